@@ -1,0 +1,169 @@
+/*
+ * sandcrate_hip.h -- C ABI of libsandcrate_hip.so: the MI355X (gfx950) implementation of
+ * SandCrate's per-timestep particle update.
+ *
+ * The reference has no FFI (it is pure Python/NumPy); this header is the boundary a
+ * maintainer binds with ctypes (INTEGRATION.md shows the stub).  Each entry point names the
+ * reference code it replaces as  file:line  relative to the reference repository.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative SC_ERR_* otherwise; the message of the
+ *     last failure on the calling thread is sc_last_error().  Nothing throws across the ABI and
+ *     nothing calls back into the host language.
+ *   - host arrays are caller-allocated, C-contiguous, float64 / int64 / int32 exactly as NumPy
+ *     holds them (particles are P x 2 interleaved x,y like crate.py:24-25); the library owns all
+ *     device memory.  Device state is float64 SoA (x, y, vx, vy) in cell-sorted order plus a
+ *     per-particle id that remembers the reference's particle index order.
+ *   - one context per GPU, one calling thread per context.  Calls are enqueued on the context's
+ *     HIP stream and return before the GPU finishes unless the description says "synchronises".
+ */
+#ifndef SANDCRATE_HIP_H
+#define SANDCRATE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_ABI_VERSION 1
+#define SC_MAX_NEIGHBORS 20 /* collision_detector.py:6  MAX_ALLOWED_NEIGHBORS */
+#define SC_MAX_SEGMENTS 16  /* wall segments of all rigid bodies together (scenes use 6 and 8) */
+#define SC_MAX_BODIES 8
+
+enum {
+  SC_OK = 0,
+  SC_ERR_ARG = -1,      /* bad argument */
+  SC_ERR_HIP = -2,      /* HIP runtime failure, see sc_last_error() */
+  SC_ERR_CAPACITY = -3, /* more particles / cells than the context was created for */
+  SC_ERR_STATE = -4,    /* call order violated (e.g. sc_step_finish without sc_step_begin) */
+  SC_ERR_DOMAIN = -5    /* a particle fell outside the cell grid (NaN or runaway position) */
+};
+
+/* Collider noise of crate.py:169 ((rand(C_i,2) - 0.5) * diameter * collider_noise_level). */
+enum {
+  SC_NOISE_NONE = 0,    /* eta = 0 (what collider_noise_level = 0 gives) */
+  SC_NOISE_HOST = 1,    /* uniforms supplied per tick by sc_set_noise_host: the host's MT19937 stream */
+  SC_NOISE_COUNTER = 2  /* counter-based hash of (seed, tick, particle id, slot); no host traffic */
+};
+
+/* Live-editable coefficients: the YAML keys of config/ *.yaml:10-22 that the tick reads
+ * (crate.py:55-57).  spring_* are inert in the reference (crate.py:117-118) and absent here. */
+typedef struct sc_params {
+  double dt;
+  double particle_radius;
+  double wall_collision_decay;
+  double pressure_amplifier;
+  double ignored_pressure;
+  double collider_noise_level;
+  double viscosity;
+  double surface_smoothing;
+  double target_pressure;
+  double gravity_x;
+  double gravity_y;
+} sc_params;
+
+/* One rigid body after RigidBody.apply_velocity (rigid_body.py:42-46, :64-68): what
+ * calc_body_points_velocities (rigid_body.py:28-34) needs, and how many of the stacked
+ * segments (crate.py:69-71) belong to it. */
+typedef struct sc_body {
+  double position_x, position_y;
+  double center_velocity_x, center_velocity_y;
+  double angular_clockwise_velocity;
+  int32_t n_segments;
+  int32_t reserved;
+} sc_body;
+
+typedef struct sc_stats {
+  int64_t particles;      /* P after remove_particles (crate.py:149-159) */
+  int64_t neighbor_slots; /* sum of C_i: how many (rand, rand) pairs crate.py:169 draws this tick */
+  int32_t max_neighbors;  /* max C_i */
+  int32_t wall_particles; /* particles with at least one wall contact (crate.py:229) */
+  int32_t flags;          /* nonzero: SC_ERR_DOMAIN condition seen on the device */
+  int32_t reserved;
+} sc_stats;
+
+typedef struct sc_ctx sc_ctx;
+
+const char* sc_last_error(void);
+int sc_abi_version(void);
+
+/* Lifetime.  capacity = most particles the context will ever hold (Crate: max_particles). */
+int sc_create(int device, int64_t capacity, sc_ctx** out);
+int sc_destroy(sc_ctx* ctx);
+/* Run on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) instead of the
+ * context's own stream.  NULL restores the own stream. */
+int sc_set_stream(sc_ctx* ctx, void* hip_stream);
+
+/* State in/out.  Replaces direct assignment of Crate.particles / particle_velocities
+ * (crate.py:24-25).  Particle i gets id i; ids order ties exactly like the reference's
+ * array index does (collision_detector.py:127 lexsort is stable). */
+int sc_upload_state(sc_ctx* ctx, const double* xy, const double* vxy, int64_t n);
+/* crate.py:138-147 create_new_particles: appended particles get the next ids. */
+int sc_append_particles(sc_ctx* ctx, const double* xy, const double* vxy, int64_t n);
+/* Synchronises.  Number of live particles. */
+int sc_count(sc_ctx* ctx, int64_t* n);
+/* Synchronises.  Writes live particles in id order (= the reference's array order): xy, vxy are
+ * n x 2, pressure (crate.py:275 particles_pressure) and ids are n.  Any pointer may be NULL.
+ * n_capacity is the room in the host arrays; *n_out is what was written. */
+int sc_download_state(sc_ctx* ctx, double* xy, double* vxy, double* pressure, int64_t* ids,
+                      int64_t n_capacity, int64_t* n_out);
+
+/* Per-tick inputs.  Coefficients are re-sent every tick because the viewer edits them live
+ * (playback.py:221-226); segments because bodies move (crate.py:363-365). */
+int sc_set_params(sc_ctx* ctx, const sc_params* p);
+/* segments: n_segments x 2 x 2 (crate.py:69-71); padded: 2*n_segments x 2 x 2 from pad_segments
+ * (geometry_utils.py:146-172), computed on the host because it is O(S). */
+int sc_set_segments(sc_ctx* ctx, const double* segments, const double* padded, int32_t n_segments,
+                    const sc_body* bodies, int32_t n_bodies);
+int sc_set_noise_mode(sc_ctx* ctx, int mode, uint64_t seed);
+
+/* The tick: crate.py:91-129 from remove_particles on.
+ *   sc_step_begin  : remove_particles (:149-159), calc_virtual_colliders + hard wall fix (:97-99,
+ *                    :202-243), strip sort + neighbor lists (collision_detector.py:9-49)
+ *   sc_step_stats  : synchronises; P and sum C_i, so the host can draw rand(sum C_i, 2)
+ *   sc_set_noise_host: those uniforms, (n_pairs x 2) in particle-index order, slot-minor (:169)
+ *   sc_step_finish : populate_colliders ... apply_particles_velocity (:103-125)
+ * sc_step(ctx, k) = k x (begin, finish) with no synchronisation; not valid in SC_NOISE_HOST mode. */
+int sc_step_begin(sc_ctx* ctx);
+int sc_step_stats(sc_ctx* ctx, sc_stats* out);
+int sc_set_noise_host(sc_ctx* ctx, const double* u01, int64_t n_pairs);
+int sc_step_finish(sc_ctx* ctx);
+int sc_step(sc_ctx* ctx, int32_t n_ticks);
+int sc_synchronize(sc_ctx* ctx);
+
+/* Parity taps, valid between sc_step_begin and sc_step_finish.  Synchronise.  All arrays have one
+ * entry per sorted slot k = 0..P-1 (the order of collision_detector.py:127):
+ *   y_floored[k]  row index floor(y/d) (collision_detector.py:126)
+ *   ids[k]        particle id in that slot (= sorted_indices when ids are array indices)
+ *   counts[k]     C of that particle, neighbors[k*20 + s] the id of its s-th neighbor or -1
+ *   fixed_xy[k*2] position after apply_hard_wall_fix (crate.py:202-211) */
+int sc_download_sort(sc_ctx* ctx, int64_t* y_floored, int64_t* ids, int64_t n_capacity, int64_t* n_out);
+int sc_download_neighbors(sc_ctx* ctx, int64_t* ids, int32_t* counts, int64_t* neighbors, double* fixed_xy,
+                          int64_t n_capacity, int64_t* n_out);
+/* After sc_step_finish: surface normals s_i of apply_tension pass 1 (crate.py:337-342) in id order. */
+int sc_download_normals(sc_ctx* ctx, double* sxy, int64_t n_capacity, int64_t* n_out);
+
+/* Stand-alone forms of two reference functions (its tests/test_distance.py pins both).
+ * sc_neighbor_search = detect_particle_collisions (collision_detector.py:9-49) on arbitrary
+ * coordinates: y_floored/sorted_indices per sorted slot, counts[i] and table[i*20+s] per ORIGINAL
+ * index i, -1 padded.  sc_points_to_segments = points_to_segments_distance
+ * (geometry_utils.py:7-39): nearest is n x s x 2, distances n x s. */
+int sc_neighbor_search(int device, const double* xy, int64_t n, double diameter, int64_t* y_floored,
+                       int64_t* sorted_indices, int32_t* counts, int64_t* table);
+int sc_points_to_segments(int device, const double* xy, int64_t n, const double* segments, int32_t n_segments,
+                          double* nearest, double* distances);
+
+/* Kernel timing with HIP events on the context's stream.  While enabled every kernel launch is
+ * bracketed by two events; sc_get_timing synchronises and returns, per kernel, the summed
+ * milliseconds and the number of launches since sc_reset_timing.  Names: sc_kernel_name(i). */
+#define SC_NUM_KERNELS 9
+int sc_enable_timing(sc_ctx* ctx, int on);
+int sc_reset_timing(sc_ctx* ctx);
+int sc_get_timing(sc_ctx* ctx, double* ms /*[SC_NUM_KERNELS]*/, int64_t* launches /*[SC_NUM_KERNELS]*/);
+const char* sc_kernel_name(int index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SANDCRATE_HIP_H */

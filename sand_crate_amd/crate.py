@@ -1,0 +1,245 @@
+"""`Crate`: the reference's simulation object (``src/crate/crate.py:19-371``) with the per-timestep
+particle update running on an MI355X.
+
+Drop-in surface: ``Crate(world_config)``, ``physics_tick()``, and the
+attributes the viewer reads or writes between ticks -- ``particles``, ``particle_velocities``,
+``particles_pressure``, ``particle_radius``, ``segments``, ``gravity``, every YAML coefficient by
+name, ``editable_coefficients()``, ``debug_arrows``, ``debug_prints``, ``tick``,
+``particle_count``, ``diameter``, ``rigid_bodies``, ``particle_sources``.
+
+What runs where
+---------------
+host   particle sources (particle_source.py), rigid-body motion (rigid_body.py), pad_segments:
+       O(new particles) and O(S) per tick, and they own the global NumPy RNG stream.
+GPU    everything per particle: removal, wall contacts + hard wall fix, strip sort and neighbor
+       lists, pressure / tension / gravity / viscosity / wall bounce / continuous collision,
+       integration (sand_crate_amd/csrc/sc_kernels.h).  State stays on the device; the
+       ``particles`` / ``particle_velocities`` / ``particles_pressure`` attributes download
+       lazily, once per tick, when read.
+
+Collider noise (crate.py:169) has three modes:
+``"host"``    (default) the host draws ``rand(sum C_i, 2)`` from the global MT19937 stream each
+              tick, exactly the numbers the reference draws particle by particle -- costs one
+              device->host count and one upload per tick;
+``"counter"`` a counter-based hash on the device keyed by (seed, tick, particle id, slot): same
+              distribution, different numbers, no host round trip (used for throughput runs);
+``"none"``    no noise (what ``collider_noise_level = 0`` computes).
+
+There is no CPU implementation behind this class: without libsandcrate_hip.so and a GPU it raises.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import yaml
+
+from . import _native as N
+from .engine import Engine
+from .load_config import WorldConfig
+from .particle_source import build_particle_sources
+from .rigid_body import build_rigid_bodies
+from .utils.geometry_utils import pad_segments
+
+_NOISE_MODES = {"none": N.NOISE_NONE, "host": N.NOISE_HOST, "counter": N.NOISE_COUNTER}
+_TICK_COEFFICIENTS = ("dt", "particle_radius", "wall_collision_decay", "pressure_amplifier", "ignored_pressure",
+                      "collider_noise_level", "viscosity", "surface_smoothing", "target_pressure")
+
+
+class Crate:
+    def __init__(self, world_config: WorldConfig, *, device: int = 0, noise: str = "host", noise_seed: int = 0,
+                 capacity: int | None = None) -> None:
+        if noise not in _NOISE_MODES:
+            raise ValueError(f"noise must be one of {sorted(_NOISE_MODES)}")
+        np.random.seed(0)  # the reference seeds the global legacy RNG here (crate.py:22)
+        self.tick: int = 0
+        self.debug_arrows: list = []
+        self.debug_prints: str = ""
+        self.world_config = world_config
+        self.rigid_bodies = build_rigid_bodies(world_config.rigid_bodies)
+        self.particle_sources = build_particle_sources(world_config.particle_sources)
+        for name in self.editable_coefficients():
+            setattr(self, name, world_config.coefficients[name])
+        self.gravity = np.array(world_config.coefficients["gravity"])
+
+        cap = capacity if capacity is not None else int(self.max_particles) + 1024
+        self._engine = Engine(max(int(cap), 1), device=device)
+        self._noise = noise
+        self._noise_seed = noise_seed
+        self._engine.set_noise_mode(_NOISE_MODES[noise], noise_seed)
+        self._count = 0            # particles on the device after the last tick / upload
+        self._count_known = True
+        self._cache = None         # (particles, velocities, pressure) downloaded for this tick
+        self._empty()
+        self._tick_seconds = 0.0   # EMA of wall time per tick, for debug_prints
+        self.last_stats = None
+
+    # ------------------------------------------------------------------ reference accessors
+    def editable_coefficients(self) -> list[str]:
+        return list(self.world_config.coefficients.keys())
+
+    @property
+    def diameter(self) -> float:
+        return self.particle_radius * 2
+
+    @property
+    def segments(self) -> np.ndarray:
+        return np.vstack([body.segments for body in self.rigid_bodies])
+
+    @property
+    def particle_count(self) -> int:
+        if not self._count_known:
+            self._count = self._engine.count()
+            self._count_known = True
+        return self._count
+
+    # ------------------------------------------------------------------ state attributes
+    def _empty(self) -> None:
+        self._cache = (np.zeros((0, 2)), np.zeros((0, 2)), np.zeros((0,)))
+
+    def _state(self):
+        if self._cache is None:
+            p, v, pr, _ = self._engine.download()
+            self._cache = (p, v, pr)
+            self._count, self._count_known = len(p), True
+        return self._cache
+
+    @property
+    def particles(self) -> np.ndarray:
+        return self._state()[0]
+
+    @particles.setter
+    def particles(self, value) -> None:
+        value = np.array(value, dtype=np.float64).reshape(-1, 2)
+        vel = self._state()[1]
+        if len(vel) != len(value):
+            vel = np.zeros_like(value)
+        self._set_state(value, vel)
+
+    @property
+    def particle_velocities(self) -> np.ndarray:
+        return self._state()[1]
+
+    @particle_velocities.setter
+    def particle_velocities(self, value) -> None:
+        value = np.array(value, dtype=np.float64).reshape(-1, 2)
+        pos = self._state()[0]
+        if len(pos) != len(value):
+            raise ValueError("set particles before particle_velocities when the particle count changes")
+        self._set_state(pos, value)
+
+    @property
+    def particles_pressure(self) -> np.ndarray:
+        return self._state()[2]
+
+    def _set_state(self, particles: np.ndarray, velocities: np.ndarray) -> None:
+        if len(particles) > self._engine.capacity:
+            self._grow(len(particles))
+        self._engine.upload(particles, velocities)
+        self._cache = (particles, velocities, np.zeros(len(particles)))
+        self._count, self._count_known = len(particles), True
+
+    def _grow(self, needed: int) -> None:
+        p, v, _ = self._state() if self._count else (np.zeros((0, 2)), np.zeros((0, 2)), None)
+        old = self._engine
+        self._engine = Engine(int(needed * 1.5) + 1024, device=old.device)
+        self._engine.set_noise_mode(_NOISE_MODES[self._noise], self._noise_seed)
+        old.close()
+        if len(p):
+            self._engine.upload(p, v)
+
+    # ------------------------------------------------------------------ the tick
+    def physics_tick(self) -> None:
+        t0 = time.perf_counter()
+        self._create_new_particles()
+        self.debug_arrows = []
+        for body in self.rigid_bodies:  # crate.py:363-365
+            body.apply_velocity(self.dt)
+        self._send_tick_inputs()
+        eng = self._engine
+        if self._noise == "host":
+            eng.step_begin()
+            stats = eng.step_stats()
+            self.last_stats = stats
+            # crate.py:165-170 draws rand(C_i, 2) particle by particle; one block is the same stream
+            eng.set_noise_host(np.random.rand(stats.neighbor_slots, 2))
+            eng.step_finish()
+            self._count, self._count_known = stats.particles, True
+        else:
+            eng.step(1)
+            self._count_known = False
+        for body in self.rigid_bodies:  # crate.py:311-314: gravity accelerates free bodies
+            if body.moves and not body.driven:
+                body.center_velocity = body.center_velocity + self.dt * self.gravity
+        self._cache = None
+        self.tick += 1
+        dt_wall = time.perf_counter() - t0
+        self._tick_seconds = 0.9 * self._tick_seconds + 0.1 * dt_wall
+        self.set_debug_prints()
+
+    def run(self, n_ticks: int) -> None:
+        """`n_ticks` ticks back to back without touching the host state in between (no sources
+        may be active, noise must not be "host"): the throughput path bench.py measures."""
+        if self._noise == "host":
+            raise RuntimeError("Crate.run needs noise='counter' or 'none'")
+        if any(src.active_ticks > self.tick for src in self.particle_sources):
+            raise RuntimeError("Crate.run cannot interleave particle sources; use physics_tick()")
+        for _ in range(n_ticks):
+            for body in self.rigid_bodies:
+                body.apply_velocity(self.dt)
+            self._send_tick_inputs()
+            self._engine.step(1)
+            self.tick += 1
+        self._cache = None
+        self._count_known = False
+
+    def synchronize(self) -> None:
+        self._engine.synchronize()
+
+    def _create_new_particles(self) -> None:
+        """crate.py:138-147: sources append in order, each seeing the count the previous left."""
+        for source in self.particle_sources:
+            if source.active_ticks <= self.tick:
+                continue
+            new_p, new_v = source.generate_particles(dt=self.dt, max_particles=self.max_particles - self.particle_count)
+            if new_p is not None:
+                if self._count + len(new_p) > self._engine.capacity:
+                    self._grow(self._count + len(new_p))
+                self._engine.append(new_p, new_v)
+                self._count += len(new_p)
+                self._cache = None
+
+    def _send_tick_inputs(self) -> None:
+        coef = {name: getattr(self, name) for name in _TICK_COEFFICIENTS}
+        self._engine.set_params(gravity=self.gravity, **coef)
+        bodies = self.rigid_bodies
+        if bodies:
+            seg = self.segments
+            self._engine.set_segments(
+                seg, pad_segments(seg, self.particle_radius),
+                [(b.position, b.center_velocity, b.angular_clockwise_velocity, len(b)) for b in bodies])
+        else:
+            self._engine.set_segments(np.zeros((0, 2, 2)), np.zeros((0, 2, 2)), [])
+
+    # ------------------------------------------------------------------ HUD text (crate.py:131-136)
+    def set_debug_prints(self) -> None:
+        count = self._count if self._count_known else "?"
+        self.debug_prints = f"Tick: {self.tick}\nParticles: {count}\n"
+        ms = 1000 * self._tick_seconds
+        self.debug_prints += yaml.dump({"Timing": {"tick (host wall, EMA)": f"{ms:.2f} ms"},
+                                        "FPS": f"{int(1 / self._tick_seconds) if self._tick_seconds > 0 else 0}"})
+        self.debug_prints += f"\n\n{self.get_coefficient_debug()}"
+
+    def get_coefficient_debug(self) -> str:
+        rows = []
+        for name in self.editable_coefficients():
+            val = getattr(self, name)
+            rows.append({name: val.tolist() if isinstance(val, np.ndarray) else val})
+        return yaml.dump(rows)
+
+    def kernel_timing(self):
+        return self._engine.timing()
+
+    @property
+    def engine(self) -> Engine:
+        return self._engine

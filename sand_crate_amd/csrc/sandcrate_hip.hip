@@ -1,0 +1,854 @@
+// libsandcrate_hip.so -- host side of the C ABI declared in include/sandcrate_hip.h.
+// Owns the device memory (float64 SoA particle arrays, cell buckets, neighbor table), builds the
+// per-tick kernel argument block and enqueues the kernels of sc_kernels.h on one HIP stream.
+// gfx950 (MI355X) only; there is no CPU path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "sandcrate_hip.h"
+#include "sc_kernels.h"
+
+using namespace sc;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) return fail(SC_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+enum KernelId { K_APPEND = 0, K_WALL_BIN, K_SCAN, K_SCATTER, K_REORDER, K_NEIGHBORS, K_NOISE_OFFSETS, K_DENSITY, K_FORCE };
+const char* kKernelNames[SC_NUM_KERNELS] = {"append",    "wall_bin",      "cell_scan", "scatter", "reorder",
+                                            "neighbors", "noise_offsets", "density",   "force_integrate"};
+
+// Largest s with sqrt(s) <= R.  sqrt is correctly rounded and monotone, so for s >= 0
+// (sqrt(s) <= R) == (s <= threshold): the kernels compare squared distances and skip the sqrt
+// while taking exactly the reference's decision (collision_detector.py:78-79, crate.py:229).
+double sq_threshold(double R) {
+  if (!(R >= 0)) return -1.0;
+  if (std::isinf(R)) return R;
+  double t = R * R;
+  const double inf = std::numeric_limits<double>::infinity();
+  while (std::sqrt(t) > R) t = std::nextafter(t, -inf);
+  while (std::sqrt(std::nextafter(t, inf)) <= R) t = std::nextafter(t, inf);
+  return t;
+}
+
+uint64_t host_mix64(uint64_t z) {
+  z ^= z >> 33;
+  z *= 0xFF51AFD7ED558CCDull;
+  z ^= z >> 33;
+  z *= 0xC4CEB9FE1A85EC53ull;
+  z ^= z >> 33;
+  return z;
+}
+
+template <class T>
+hipError_t dalloc(T** p, size_t n) {
+  return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T));
+}
+
+}  // namespace
+
+struct sc_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  int64_t cap = 0;
+  // particle sets: [0] storage order (input of a tick, output of pass B), [1] cell-sorted
+  double *x[2] = {}, *y[2] = {}, *vx[2] = {}, *vy[2] = {};
+  int* id[2] = {};
+  int *cellS = nullptr, *wslotS = nullptr, *cellT = nullptr, *wslotT = nullptr, *perm = nullptr;
+  int *cellCount = nullptr, *cellStart = nullptr, *blockSums = nullptr;
+  int64_t cellAlloc = 0;
+  double* wrec = nullptr;
+  int* nbr = nullptr;
+  unsigned char* cnt = nullptr;
+  double *P = nullptr, *sx = nullptr, *sy = nullptr;
+  int* counters = nullptr;
+  // SC_NOISE_HOST
+  int *cntById = nullptr, *offById = nullptr, *idBlockSums = nullptr;
+  int64_t idAlloc = 0;
+  double* eta = nullptr;
+  int64_t etaAlloc = 0, etaPairs = 0;
+  // staging for uploads
+  double *stage_xy = nullptr, *stage_vxy = nullptr;
+  int64_t stageAlloc = 0;
+
+  sc_params params{};
+  bool have_params = false;
+  int nseg = 0, nbody = 0;
+  Seg seg[kMaxSeg]{};
+  Seg pad[2 * kMaxSeg]{};
+  BodyK body[kMaxBody]{};
+  int noise_mode = SC_NOISE_NONE;
+  uint64_t seed = 0;
+  int64_t tick = 0;
+  int64_t upper = 0;    // host-side upper bound of the stored particle count
+  int64_t next_id = 0;
+  bool in_step = false;
+  int64_t normals_valid = 0;
+  bool custom_grid = false;  // sc_neighbor_search: grid from the data, no walls, no removal
+  long long grid_row0 = 0, grid_col0 = 0;
+  int grid_nrows = 0, grid_ncols = 0;
+  double custom_d = 0;
+  World w{};
+
+  bool timing = false;
+  struct Ev {
+    hipEvent_t a, b;
+    int k;
+  };
+  std::vector<Ev> ev_used, ev_free;
+  double ms[SC_NUM_KERNELS] = {};
+  int64_t launches[SC_NUM_KERNELS] = {};
+};
+
+namespace {
+
+struct Bracket {  // two HIP events around a launch when timing is on
+  sc_ctx* c;
+  sc_ctx::Ev ev{};
+  bool on;
+  Bracket(sc_ctx* ctx, int k) : c(ctx), on(ctx->timing) {
+    if (!on) return;
+    if (!c->ev_free.empty()) {
+      ev = c->ev_free.back();
+      c->ev_free.pop_back();
+    } else if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) {
+      on = false;
+      return;
+    }
+    ev.k = k;
+    (void)hipEventRecord(ev.a, c->stream);
+  }
+  ~Bracket() {
+    if (!on) return;
+    (void)hipEventRecord(ev.b, c->stream);
+    c->ev_used.push_back(ev);
+  }
+};
+
+int grid_for(int64_t n) { return (int)std::max<int64_t>(1, (n + kBlock - 1) / kBlock); }
+
+int ensure_cells(sc_ctx* c, int64_t ncells) {
+  if (ncells + 1 <= c->cellAlloc) return SC_OK;
+  if (ncells > (int64_t)1 << 28) return fail(SC_ERR_CAPACITY, "cell grid of %lld cells is too large", (long long)ncells);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->cellCount) (void)hipFree(c->cellCount);
+  if (c->cellStart) (void)hipFree(c->cellStart);
+  if (c->blockSums) (void)hipFree(c->blockSums);
+  int64_t n = ncells + 1 + ncells / 4;
+  HIPCHK(dalloc(&c->cellCount, n));
+  HIPCHK(dalloc(&c->cellStart, n + 1));
+  HIPCHK(dalloc(&c->blockSums, n / kScanPerBlock + 2));
+  HIPCHK(hipMemsetAsync(c->cellCount, 0, n * sizeof(int), c->stream));
+  c->cellAlloc = n;
+  return SC_OK;
+}
+
+int ensure_ids(sc_ctx* c, int64_t n) {
+  if (n <= c->idAlloc) return SC_OK;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->cntById) (void)hipFree(c->cntById);
+  if (c->offById) (void)hipFree(c->offById);
+  if (c->idBlockSums) (void)hipFree(c->idBlockSums);
+  int64_t m = n + n / 2 + 1024;
+  HIPCHK(dalloc(&c->cntById, m));
+  HIPCHK(dalloc(&c->offById, m + 1));
+  HIPCHK(dalloc(&c->idBlockSums, m / kScanPerBlock + 2));
+  c->idAlloc = m;
+  return SC_OK;
+}
+
+int ensure_stage(sc_ctx* c, int64_t n) {
+  if (n <= c->stageAlloc) return SC_OK;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->stage_xy) (void)hipFree(c->stage_xy);
+  if (c->stage_vxy) (void)hipFree(c->stage_vxy);
+  int64_t m = n + n / 2 + 256;
+  HIPCHK(dalloc(&c->stage_xy, 2 * m));
+  HIPCHK(dalloc(&c->stage_vxy, 2 * m));
+  c->stageAlloc = m;
+  return SC_OK;
+}
+
+// exclusive scan of in[0..n) into out[0..n], out[n] = total (also to *total_out if given)
+int launch_scan(sc_ctx* c, const int* in, int* out, int64_t n, int* blockSums, int* total_out) {
+  int nb = (int)((n + kScanPerBlock - 1) / kScanPerBlock);
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(kBlock), 0, c->stream, in, out, (int)n, blockSums);
+  hipLaunchKernelGGL(k_scan_fix, dim3(nb), dim3(kBlock), 0, c->stream, out, (int)n, blockSums, nb, total_out);
+  HIPCHK(hipGetLastError());
+  return SC_OK;
+}
+
+// Kernel-argument block of this tick.  The cell grid covers [-r, 1+r]^2 -- where
+// remove_particles (crate.py:152) leaves particles -- plus three cells of margin for the hard wall
+// fix, plus a ring of always-empty cells so that c-1 / c+1 / c+-ncols never leave the arrays.
+int make_world(sc_ctx* c) {
+  World& w = c->w;
+  std::memset(&w, 0, sizeof w);
+  const double inf = std::numeric_limits<double>::infinity();
+  if (c->custom_grid) {
+    w.d = c->custom_d;
+    w.r = w.d / 2;
+    w.lo = -inf;
+    w.hi = inf;
+    w.row0 = c->grid_row0;
+    w.col0 = c->grid_col0;
+    w.nrows = c->grid_nrows;
+    w.ncols = c->grid_ncols;
+    w.t_nbr = sq_threshold(w.d);
+    w.t_wall = -1.0;
+    w.far_box = w.touch_box = -1.0;
+    w.ccd_skip2 = inf;
+  } else {
+    if (!c->have_params) return fail(SC_ERR_STATE, "sc_set_params has not been called");
+    const sc_params& p = c->params;
+    if (!(p.particle_radius > 0) || !std::isfinite(p.particle_radius))
+      return fail(SC_ERR_ARG, "particle_radius must be positive and finite");
+    w.dt = p.dt;
+    w.r = p.particle_radius;
+    w.d = p.particle_radius * 2;  // crate.py:65-67
+    w.decay = p.wall_collision_decay;
+    w.pamp = p.pressure_amplifier;
+    w.ignored = p.ignored_pressure;
+    w.level = p.collider_noise_level;
+    w.visc = p.viscosity;
+    w.ss = p.surface_smoothing;
+    w.tp = p.target_pressure;
+    w.gx = p.gravity_x;
+    w.gy = p.gravity_y;
+    w.lo = -w.r;    // crate.py:152
+    w.hi = 1 + w.r;
+    w.t_nbr = sq_threshold(w.d);
+    double r12 = w.r * 1.2;  // crate.py:229
+    w.t_wall = sq_threshold(r12);
+    w.touch_box = r12 * (1 + 1e-6) + 1e-12;
+    w.far_box = (w.r + 2 * w.d) * (1 + 1e-6) + 1e-12;
+    w.ccd_skip2 = (2 * w.d) * (2 * w.d) * (1 - 1e-6);
+    long long cmin = (long long)std::floor(w.lo / w.d) - 3;
+    long long cmax = (long long)std::floor(w.hi / w.d) + 3;
+    w.row0 = w.col0 = cmin - 1;
+    w.nrows = w.ncols = (int)(cmax - cmin + 1) + 2;
+  }
+  w.nseg = c->nseg;
+  w.nbody = c->nbody;
+  std::memcpy(w.seg, c->seg, sizeof w.seg);
+  std::memcpy(w.pad, c->pad, sizeof w.pad);
+  std::memcpy(w.body, c->body, sizeof w.body);
+  w.noise_mode = c->noise_mode;
+  w.tick = (int)c->tick;
+  w.noise_key = host_mix64(c->seed + (uint64_t)(c->tick + 1) * 0x9E3779B97F4A7C15ull);
+  w.own_lo = std::numeric_limits<long long>::min();
+  w.own_hi = std::numeric_limits<long long>::max();
+  return ensure_cells(c, (int64_t)w.nrows * w.ncols);
+}
+
+int read_counters(sc_ctx* c, int* out) {
+  HIPCHK(hipMemcpyAsync(out, c->counters, C_COUNT * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return SC_OK;
+}
+
+int check_flags(int flags) {
+  if (flags & F_NAN)
+    return fail(SC_ERR_DOMAIN, "a particle position became NaN (zero distance to a wall, crate.py:206); it was dropped");
+  if (flags & F_OUT_OF_GRID) return fail(SC_ERR_DOMAIN, "a particle left the cell grid; it was dropped");
+  return SC_OK;
+}
+
+int put_particles(sc_ctx* c, const double* xy, const double* vxy, int64_t n, bool reset) {
+  if (n < 0 || (n > 0 && (!xy || !vxy))) return fail(SC_ERR_ARG, "bad particle arrays");
+  if (c->in_step) return fail(SC_ERR_STATE, "particles cannot change between sc_step_begin and sc_step_finish");
+  int64_t base = reset ? 0 : c->upper;
+  if (base + n > c->cap)
+    return fail(SC_ERR_CAPACITY, "%lld particles exceed the context capacity %lld", (long long)(base + n), (long long)c->cap);
+  if (reset) {
+    c->next_id = 0;
+    c->normals_valid = 0;
+  }
+  if (c->next_id + n > std::numeric_limits<int>::max()) return fail(SC_ERR_CAPACITY, "particle ids exhausted");
+  if (n > 0) {
+    int rc = ensure_stage(c, n);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->stage_xy, xy, 2 * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->stage_vxy, vxy, 2 * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    Bracket br(c, K_APPEND);
+    hipLaunchKernelGGL(k_append, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, c->stage_xy, c->stage_vxy, (int)n,
+                       (int)c->next_id, c->counters, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], reset ? 1 : 0);
+  }
+  hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, c->stream, c->counters, (int)n, reset ? 1 : 0);
+  HIPCHK(hipGetLastError());
+  c->upper = base + n;
+  c->next_id += n;
+  return SC_OK;
+}
+
+template <int NOISE>
+void launch_finish(sc_ctx* c, int grid, int cap) {
+  {
+    Bracket br(c, K_DENSITY);
+    hipLaunchKernelGGL(k_density<NOISE>, dim3(grid), dim3(kBlock), 0, c->stream, c->w, c->counters, c->x[1], c->y[1],
+                       c->id[1], c->nbr, c->cnt, cap, c->eta, c->offById, c->P, c->sx, c->sy);
+  }
+  {
+    Bracket br(c, K_FORCE);
+    hipLaunchKernelGGL(k_force<NOISE>, dim3(grid), dim3(kBlock), 0, c->stream, c->w, c->counters, c->x[1], c->y[1],
+                       c->vx[1], c->vy[1], c->id[1], c->wslotT, c->nbr, c->cnt, cap, c->eta, c->offById, c->P, c->sx,
+                       c->sy, c->wrec, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0]);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sc_last_error(void) { return g_err.c_str(); }
+int sc_abi_version(void) { return SC_ABI_VERSION; }
+const char* sc_kernel_name(int i) { return (i >= 0 && i < SC_NUM_KERNELS) ? kKernelNames[i] : ""; }
+
+int sc_create(int device, int64_t capacity, sc_ctx** out) {
+  if (!out || capacity < 1 || capacity > (int64_t)100000000) return fail(SC_ERR_ARG, "bad capacity");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(SC_ERR_ARG, "device %d of %d", device, ndev);
+  HIPCHK(hipSetDevice(device));
+  sc_ctx* c = new sc_ctx();
+  c->device = device;
+  c->cap = capacity;
+  size_t n = (size_t)capacity;
+  hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  c->stream = c->own_stream;
+  for (int s = 0; s < 2 && e == hipSuccess; ++s) {
+    if (e == hipSuccess) e = dalloc(&c->x[s], n);
+    if (e == hipSuccess) e = dalloc(&c->y[s], n);
+    if (e == hipSuccess) e = dalloc(&c->vx[s], n);
+    if (e == hipSuccess) e = dalloc(&c->vy[s], n);
+    if (e == hipSuccess) e = dalloc(&c->id[s], n);
+  }
+  if (e == hipSuccess) e = dalloc(&c->cellS, n);
+  if (e == hipSuccess) e = dalloc(&c->wslotS, n);
+  if (e == hipSuccess) e = dalloc(&c->cellT, n);
+  if (e == hipSuccess) e = dalloc(&c->wslotT, n);
+  if (e == hipSuccess) e = dalloc(&c->perm, n);
+  if (e == hipSuccess) e = dalloc(&c->wrec, 5 * n);
+  if (e == hipSuccess) e = dalloc(&c->nbr, (size_t)kMaxNbr * n);
+  if (e == hipSuccess) e = dalloc(&c->cnt, n);
+  if (e == hipSuccess) e = dalloc(&c->P, n);
+  if (e == hipSuccess) e = dalloc(&c->sx, n);
+  if (e == hipSuccess) e = dalloc(&c->sy, n);
+  if (e == hipSuccess) e = dalloc(&c->counters, (size_t)C_COUNT);
+  if (e == hipSuccess) e = hipMemsetAsync(c->counters, 0, C_COUNT * sizeof(int), c->stream);
+  if (e != hipSuccess) {
+    int rc = fail(SC_ERR_HIP, "sc_create: %s", hipGetErrorString(e));
+    sc_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return SC_OK;
+}
+
+int sc_destroy(sc_ctx* c) {
+  if (!c) return SC_OK;
+  (void)hipSetDevice(c->device);
+  if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  for (int s = 0; s < 2; ++s) {
+    (void)hipFree(c->x[s]);
+    (void)hipFree(c->y[s]);
+    (void)hipFree(c->vx[s]);
+    (void)hipFree(c->vy[s]);
+    (void)hipFree(c->id[s]);
+  }
+  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->cellCount, c->cellStart, c->blockSums, c->wrec,
+                  c->nbr, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
+                  c->stage_xy, c->stage_vxy};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (auto& v : {c->ev_used, c->ev_free})
+    for (auto& e : v) {
+      (void)hipEventDestroy(e.a);
+      (void)hipEventDestroy(e.b);
+    }
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return SC_OK;
+}
+
+int sc_set_stream(sc_ctx* c, void* s) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return SC_OK;
+}
+
+int sc_upload_state(sc_ctx* c, const double* xy, const double* vxy, int64_t n) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  HIPCHK(hipSetDevice(c->device));
+  return put_particles(c, xy, vxy, n, true);
+}
+
+int sc_append_particles(sc_ctx* c, const double* xy, const double* vxy, int64_t n) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  HIPCHK(hipSetDevice(c->device));
+  return put_particles(c, xy, vxy, n, false);
+}
+
+int sc_synchronize(sc_ctx* c) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  int h[C_COUNT];
+  int rc = read_counters(c, h);
+  if (rc) return rc;
+  if (!c->in_step) c->upper = h[C_NS];
+  if (h[C_FLAGS]) {
+    HIPCHK(hipMemsetAsync(c->counters + C_FLAGS, 0, sizeof(int), c->stream));
+    return check_flags(h[C_FLAGS]);
+  }
+  return SC_OK;
+}
+
+int sc_count(sc_ctx* c, int64_t* n) {
+  if (!c || !n) return fail(SC_ERR_ARG, "null argument");
+  int h[C_COUNT];
+  int rc = read_counters(c, h);
+  if (rc) return rc;
+  *n = c->in_step ? h[C_NT] : h[C_NS];
+  if (!c->in_step) c->upper = h[C_NS];
+  return SC_OK;
+}
+
+int sc_set_params(sc_ctx* c, const sc_params* p) {
+  if (!c || !p) return fail(SC_ERR_ARG, "null argument");
+  if (c->in_step) return fail(SC_ERR_STATE, "coefficients cannot change inside a tick");
+  c->params = *p;
+  c->have_params = true;
+  return SC_OK;
+}
+
+int sc_set_segments(sc_ctx* c, const double* segments, const double* padded, int32_t ns, const sc_body* bodies,
+                    int32_t nb) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  if (c->in_step) return fail(SC_ERR_STATE, "segments cannot change inside a tick");
+  if (ns < 0 || ns > kMaxSeg) return fail(SC_ERR_CAPACITY, "%d segments, at most %d", ns, kMaxSeg);
+  if (nb < 0 || nb > kMaxBody) return fail(SC_ERR_CAPACITY, "%d bodies, at most %d", nb, kMaxBody);
+  if (ns > 0 && (!segments || !padded)) return fail(SC_ERR_ARG, "null segment arrays");
+  int total = 0;
+  for (int b = 0; b < nb; ++b) total += bodies[b].n_segments;
+  if (nb > 0 && total != ns) return fail(SC_ERR_ARG, "bodies own %d segments, %d given", total, ns);
+  c->nseg = ns;
+  c->nbody = nb;
+  for (int k = 0; k < ns; ++k) c->seg[k] = Seg{segments[4 * k], segments[4 * k + 1], segments[4 * k + 2], segments[4 * k + 3]};
+  for (int k = 0; k < 2 * ns; ++k) c->pad[k] = Seg{padded[4 * k], padded[4 * k + 1], padded[4 * k + 2], padded[4 * k + 3]};
+  for (int b = 0; b < nb; ++b)
+    c->body[b] = BodyK{bodies[b].position_x,        bodies[b].position_y, bodies[b].center_velocity_x,
+                       bodies[b].center_velocity_y, bodies[b].angular_clockwise_velocity, bodies[b].n_segments, 0};
+  return SC_OK;
+}
+
+int sc_set_noise_mode(sc_ctx* c, int mode, uint64_t seed) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  if (mode < SC_NOISE_NONE || mode > SC_NOISE_COUNTER) return fail(SC_ERR_ARG, "noise mode %d", mode);
+  if (c->in_step) return fail(SC_ERR_STATE, "noise mode cannot change inside a tick");
+  c->noise_mode = mode;
+  c->seed = seed;
+  return SC_OK;
+}
+
+int sc_step_begin(sc_ctx* c) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  if (c->in_step) return fail(SC_ERR_STATE, "sc_step_begin called twice");
+  HIPCHK(hipSetDevice(c->device));
+  int rc = make_world(c);
+  if (rc) return rc;
+  const World& w = c->w;
+  int grid = grid_for(c->upper);
+  int cap = (int)c->cap;
+  HIPCHK(hipMemsetAsync(c->counters + C_WREC, 0, 4 * sizeof(int), c->stream));  // WREC, SUMC, MAXC, SUMC_HI
+  {
+    Bracket br(c, K_WALL_BIN);
+    hipLaunchKernelGGL(k_wall_bin, dim3(grid), dim3(kBlock), 0, c->stream, w, c->counters, c->x[0], c->y[0], c->cellS,
+                       c->wslotS, c->cellCount, c->wrec);
+  }
+  {
+    Bracket br(c, K_SCAN);
+    rc = launch_scan(c, c->cellCount, c->cellStart, (int64_t)w.nrows * w.ncols, c->blockSums, c->counters + C_NT);
+    if (rc) return rc;
+  }
+  {
+    Bracket br(c, K_SCATTER);
+    hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->cellS, c->cellStart,
+                       c->cellCount, c->perm);
+  }
+  {
+    Bracket br(c, K_REORDER);
+    hipLaunchKernelGGL(k_reorder, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->perm, c->cellS, c->cellStart,
+                       c->wslotS, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], c->x[1], c->y[1], c->vx[1], c->vy[1],
+                       c->id[1], c->cellT, c->wslotT);
+  }
+  {
+    Bracket br(c, K_NEIGHBORS);
+    hipLaunchKernelGGL(k_neighbors, dim3(grid), dim3(kBlock), 0, c->stream, w, c->counters, c->x[1], c->y[1], c->cellT,
+                       c->cellStart, c->nbr, c->cnt, cap);
+  }
+  if (c->noise_mode == SC_NOISE_HOST && c->next_id > 0) {
+    rc = ensure_ids(c, c->next_id);
+    if (rc) return rc;
+    Bracket br(c, K_NOISE_OFFSETS);
+    HIPCHK(hipMemsetAsync(c->cntById, 0, c->next_id * sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_count_by_id, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->id[1], c->cnt, c->cntById);
+    rc = launch_scan(c, c->cntById, c->offById, c->next_id, c->idBlockSums, nullptr);
+    if (rc) return rc;
+  }
+  HIPCHK(hipGetLastError());
+  c->in_step = true;
+  c->etaPairs = -1;
+  return SC_OK;
+}
+
+int sc_step_stats(sc_ctx* c, sc_stats* out) {
+  if (!c || !out) return fail(SC_ERR_ARG, "null argument");
+  if (!c->in_step) return fail(SC_ERR_STATE, "sc_step_stats needs sc_step_begin first");
+  int h[C_COUNT];
+  int rc = read_counters(c, h);
+  if (rc) return rc;
+  out->particles = h[C_NT];
+  out->neighbor_slots = (int64_t)(uint32_t)h[C_SUMC] + ((int64_t)h[C_SUMC_HI] << 32);
+  out->max_neighbors = h[C_MAXC];
+  out->wall_particles = h[C_WREC];
+  out->flags = h[C_FLAGS];
+  out->reserved = 0;
+  return SC_OK;
+}
+
+int sc_set_noise_host(sc_ctx* c, const double* u01, int64_t n_pairs) {
+  if (!c || n_pairs < 0 || (n_pairs > 0 && !u01)) return fail(SC_ERR_ARG, "bad noise array");
+  if (!c->in_step) return fail(SC_ERR_STATE, "sc_set_noise_host needs sc_step_begin first");
+  if (n_pairs > c->etaAlloc) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->eta) (void)hipFree(c->eta);
+    c->eta = nullptr;
+    int64_t m = n_pairs + n_pairs / 2 + 1024;
+    HIPCHK(dalloc(&c->eta, 2 * m));
+    c->etaAlloc = m;
+  }
+  if (n_pairs > 0)
+    HIPCHK(hipMemcpyAsync(c->eta, u01, 2 * n_pairs * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  c->etaPairs = n_pairs;
+  return SC_OK;
+}
+
+int sc_step_finish(sc_ctx* c) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  if (!c->in_step) return fail(SC_ERR_STATE, "sc_step_finish needs sc_step_begin first");
+  if (c->noise_mode == SC_NOISE_HOST && c->etaPairs < 0)
+    return fail(SC_ERR_STATE, "SC_NOISE_HOST: sc_set_noise_host must be called every tick");
+  int grid = grid_for(c->upper);
+  int cap = (int)c->cap;
+  switch (c->noise_mode) {
+    case SC_NOISE_HOST: launch_finish<SC_NOISE_HOST>(c, grid, cap); break;
+    case SC_NOISE_COUNTER: launch_finish<SC_NOISE_COUNTER>(c, grid, cap); break;
+    default: launch_finish<SC_NOISE_NONE>(c, grid, cap); break;
+  }
+  HIPCHK(hipGetLastError());
+  c->in_step = false;
+  c->tick += 1;
+  c->normals_valid = 1;
+  return SC_OK;
+}
+
+int sc_step(sc_ctx* c, int32_t n_ticks) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  if (c->noise_mode == SC_NOISE_HOST) return fail(SC_ERR_STATE, "sc_step is not available in SC_NOISE_HOST mode");
+  for (int t = 0; t < n_ticks; ++t) {
+    int rc = sc_step_begin(c);
+    if (rc) return rc;
+    rc = sc_step_finish(c);
+    if (rc) return rc;
+  }
+  return SC_OK;
+}
+
+// ---- downloads -----------------------------------------------------------------------------
+
+static int fetch(sc_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return SC_OK;
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  return SC_OK;
+}
+
+int sc_download_state(sc_ctx* c, double* xy, double* vxy, double* pressure, int64_t* ids, int64_t room, int64_t* n_out) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  if (c->in_step) return fail(SC_ERR_STATE, "sc_download_state inside a tick");
+  int h[C_COUNT];
+  int rc = read_counters(c, h);
+  if (rc) return rc;
+  int64_t n = h[C_NS];
+  c->upper = n;
+  if (n_out) *n_out = n;
+  if (n > room) return fail(SC_ERR_CAPACITY, "host arrays hold %lld, %lld particles live", (long long)room, (long long)n);
+  std::vector<double> hx(n), hy(n), hvx(n), hvy(n), hp(n, 0.0);
+  std::vector<int> hid(n);
+  size_t b = n * sizeof(double);
+  if ((rc = fetch(c, hx.data(), c->x[0], b)) || (rc = fetch(c, hy.data(), c->y[0], b)) ||
+      (rc = fetch(c, hvx.data(), c->vx[0], b)) || (rc = fetch(c, hvy.data(), c->vy[0], b)) ||
+      (rc = fetch(c, hid.data(), c->id[0], n * sizeof(int))))
+    return rc;
+  // pressure is valid for the particles of the last finished tick, which are exactly the stored
+  // ones unless particles were uploaded/appended since
+  int64_t np = c->normals_valid ? std::min<int64_t>(n, h[C_NT]) : 0;
+  if (pressure && np > 0 && (rc = fetch(c, hp.data(), c->P, np * sizeof(double)))) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::vector<int> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&](int a, int b2) { return hid[a] < hid[b2]; });
+  for (int64_t k = 0; k < n; ++k) {
+    int s = order[k];
+    if (xy) {
+      xy[2 * k] = hx[s];
+      xy[2 * k + 1] = hy[s];
+    }
+    if (vxy) {
+      vxy[2 * k] = hvx[s];
+      vxy[2 * k + 1] = hvy[s];
+    }
+    if (pressure) pressure[k] = s < np ? hp[s] : 0.0;
+    if (ids) ids[k] = hid[s];
+  }
+  if (h[C_FLAGS]) {
+    HIPCHK(hipMemsetAsync(c->counters + C_FLAGS, 0, sizeof(int), c->stream));
+    return check_flags(h[C_FLAGS]);
+  }
+  return SC_OK;
+}
+
+int sc_download_sort(sc_ctx* c, int64_t* y_floored, int64_t* ids, int64_t room, int64_t* n_out) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  if (!c->in_step) return fail(SC_ERR_STATE, "sc_download_sort is valid between sc_step_begin and sc_step_finish");
+  int h[C_COUNT];
+  int rc = read_counters(c, h);
+  if (rc) return rc;
+  int64_t n = h[C_NT];
+  if (n_out) *n_out = n;
+  if (n > room) return fail(SC_ERR_CAPACITY, "host arrays too small");
+  std::vector<int> cell(n), id(n);
+  if ((rc = fetch(c, cell.data(), c->cellT, n * sizeof(int))) || (rc = fetch(c, id.data(), c->id[1], n * sizeof(int))))
+    return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int64_t k = 0; k < n; ++k) {
+    if (y_floored) y_floored[k] = (int64_t)(cell[k] / c->w.ncols) + c->w.row0;
+    if (ids) ids[k] = id[k];
+  }
+  return SC_OK;
+}
+
+int sc_download_neighbors(sc_ctx* c, int64_t* ids, int32_t* counts, int64_t* neighbors, double* fixed_xy, int64_t room,
+                          int64_t* n_out) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  if (!c->in_step) return fail(SC_ERR_STATE, "sc_download_neighbors is valid between sc_step_begin and sc_step_finish");
+  int h[C_COUNT];
+  int rc = read_counters(c, h);
+  if (rc) return rc;
+  int64_t n = h[C_NT];
+  if (n_out) *n_out = n;
+  if (n > room) return fail(SC_ERR_CAPACITY, "host arrays too small");
+  std::vector<int> id(n);
+  std::vector<unsigned char> cnt(n);
+  std::vector<double> hx(n), hy(n);
+  std::vector<int> slot(n);
+  if ((rc = fetch(c, id.data(), c->id[1], n * sizeof(int))) || (rc = fetch(c, cnt.data(), c->cnt, n)) ||
+      (rc = fetch(c, hx.data(), c->x[1], n * sizeof(double))) || (rc = fetch(c, hy.data(), c->y[1], n * sizeof(double))))
+    return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (neighbors)
+    for (int64_t k = 0; k < n * kMaxNbr; ++k) neighbors[k] = -1;
+  for (int s = 0; s < kMaxNbr && neighbors; ++s) {
+    if ((rc = fetch(c, slot.data(), c->nbr + (size_t)s * c->cap, n * sizeof(int)))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int64_t k = 0; k < n; ++k)
+      if (s < cnt[k]) neighbors[k * kMaxNbr + s] = id[slot[k]];
+  }
+  for (int64_t k = 0; k < n; ++k) {
+    if (ids) ids[k] = id[k];
+    if (counts) counts[k] = cnt[k];
+    if (fixed_xy) {
+      fixed_xy[2 * k] = hx[k];
+      fixed_xy[2 * k + 1] = hy[k];
+    }
+  }
+  return SC_OK;
+}
+
+int sc_download_normals(sc_ctx* c, double* sxy, int64_t room, int64_t* n_out) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  if (c->in_step || !c->normals_valid) return fail(SC_ERR_STATE, "sc_download_normals needs a finished tick");
+  int h[C_COUNT];
+  int rc = read_counters(c, h);
+  if (rc) return rc;
+  int64_t n = h[C_NT];
+  if (n_out) *n_out = n;
+  if (n > room) return fail(SC_ERR_CAPACITY, "host arrays too small");
+  std::vector<double> a(n), b(n);
+  std::vector<int> id(n);
+  if ((rc = fetch(c, a.data(), c->sx, n * sizeof(double))) || (rc = fetch(c, b.data(), c->sy, n * sizeof(double))) ||
+      (rc = fetch(c, id.data(), c->id[1], n * sizeof(int))))
+    return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::vector<int> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&](int p, int q) { return id[p] < id[q]; });
+  for (int64_t k = 0; k < n && sxy; ++k) {
+    sxy[2 * k] = a[order[k]];
+    sxy[2 * k + 1] = b[order[k]];
+  }
+  return SC_OK;
+}
+
+// ---- stand-alone reference functions ----------------------------------------------------------
+
+int sc_neighbor_search(int device, const double* xy, int64_t n, double diameter, int64_t* y_floored,
+                       int64_t* sorted_indices, int32_t* counts, int64_t* table) {
+  if (n < 0 || (n > 0 && !xy) || !(diameter > 0)) return fail(SC_ERR_ARG, "bad arguments");
+  if (n == 0) return SC_OK;
+  // the grid comes from the data's bounding box; the search itself runs on the device
+  double xmin = xy[0], xmax = xy[0], ymin = xy[1], ymax = xy[1];
+  for (int64_t i = 0; i < n; ++i) {
+    double px = xy[2 * i], py = xy[2 * i + 1];
+    if (!std::isfinite(px) || !std::isfinite(py)) return fail(SC_ERR_DOMAIN, "non-finite coordinate at %lld", (long long)i);
+    xmin = std::min(xmin, px);
+    xmax = std::max(xmax, px);
+    ymin = std::min(ymin, py);
+    ymax = std::max(ymax, py);
+  }
+  double c0 = std::floor(xmin / diameter), c1 = std::floor(xmax / diameter);
+  double r0 = std::floor(ymin / diameter), r1 = std::floor(ymax / diameter);
+  if (!(std::fabs(c0) < 4e15 && std::fabs(c1) < 4e15 && std::fabs(r0) < 4e15 && std::fabs(r1) < 4e15))
+    return fail(SC_ERR_DOMAIN, "coordinates too large for the diameter");
+  double ncols = c1 - c0 + 3, nrows = r1 - r0 + 3;
+  if (ncols * nrows > (double)((int64_t)1 << 27))
+    return fail(SC_ERR_CAPACITY, "bounding box of %.0f x %.0f cells is too sparse for a uniform grid", nrows, ncols);
+  sc_ctx* c = nullptr;
+  int rc = sc_create(device, n, &c);
+  if (rc) return rc;
+  c->custom_grid = true;
+  c->custom_d = diameter;
+  c->grid_row0 = (long long)r0 - 1;
+  c->grid_col0 = (long long)c0 - 1;
+  c->grid_nrows = (int)nrows;
+  c->grid_ncols = (int)ncols;
+  std::vector<double> zero(2 * n, 0.0);
+  std::vector<int64_t> ids(n), nb((size_t)n * kMaxNbr);
+  std::vector<int32_t> cn(n);
+  int64_t got = 0;
+  if ((rc = sc_upload_state(c, xy, zero.data(), n)) == SC_OK && (rc = sc_step_begin(c)) == SC_OK &&
+      (rc = sc_download_sort(c, y_floored, sorted_indices, n, &got)) == SC_OK &&
+      (rc = sc_download_neighbors(c, ids.data(), cn.data(), nb.data(), nullptr, n, &got)) == SC_OK) {
+    if (got != n) {
+      rc = fail(SC_ERR_DOMAIN, "%lld of %lld particles were binned", (long long)got, (long long)n);
+    } else {
+      for (int64_t k = 0; k < n; ++k) {
+        int64_t i = ids[k];
+        if (counts) counts[i] = cn[k];
+        if (table) std::memcpy(table + i * kMaxNbr, nb.data() + k * kMaxNbr, kMaxNbr * sizeof(int64_t));
+      }
+    }
+  }
+  std::string keep = g_err;
+  sc_destroy(c);
+  g_err = keep;
+  return rc;
+}
+
+int sc_points_to_segments(int device, const double* xy, int64_t n, const double* segments, int32_t ns, double* nearest,
+                          double* distances) {
+  if (n < 0 || ns < 0 || (n > 0 && !xy) || (ns > 0 && !segments)) return fail(SC_ERR_ARG, "bad arguments");
+  if (n == 0 || ns == 0) return SC_OK;
+  HIPCHK(hipSetDevice(device));
+  double *dxy = nullptr, *dseg = nullptr, *dnear = nullptr, *ddist = nullptr;
+  size_t t = (size_t)n * ns;
+  hipError_t e = dalloc(&dxy, 2 * (size_t)n);
+  if (e == hipSuccess) e = dalloc(&dseg, 4 * (size_t)ns);
+  if (e == hipSuccess) e = dalloc(&dnear, 2 * t);
+  if (e == hipSuccess) e = dalloc(&ddist, t);
+  if (e == hipSuccess) e = hipMemcpy(dxy, xy, 2 * n * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dseg, segments, 4 * ns * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_points_to_segments, dim3((unsigned)((t + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0, dxy, (int)n,
+                       dseg, (int)ns, dnear, ddist);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess && nearest) e = hipMemcpy(nearest, dnear, 2 * t * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && distances) e = hipMemcpy(distances, ddist, t * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(dxy);
+  (void)hipFree(dseg);
+  (void)hipFree(dnear);
+  (void)hipFree(ddist);
+  if (e != hipSuccess) return fail(SC_ERR_HIP, "sc_points_to_segments: %s", hipGetErrorString(e));
+  return SC_OK;
+}
+
+// ---- timing -----------------------------------------------------------------------------------
+
+static int harvest(sc_ctx* c) {
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (auto& e : c->ev_used) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+      c->ms[e.k] += ms;
+      c->launches[e.k] += 1;
+    }
+    c->ev_free.push_back(e);
+  }
+  c->ev_used.clear();
+  return SC_OK;
+}
+
+int sc_enable_timing(sc_ctx* c, int on) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  if (!on && c->timing) harvest(c);
+  c->timing = on != 0;
+  return SC_OK;
+}
+
+int sc_reset_timing(sc_ctx* c) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  int rc = harvest(c);
+  for (int k = 0; k < SC_NUM_KERNELS; ++k) {
+    c->ms[k] = 0;
+    c->launches[k] = 0;
+  }
+  return rc;
+}
+
+int sc_get_timing(sc_ctx* c, double* ms, int64_t* launches) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  int rc = harvest(c);
+  for (int k = 0; k < SC_NUM_KERNELS; ++k) {
+    if (ms) ms[k] = c->ms[k];
+    if (launches) launches[k] = c->launches[k];
+  }
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// Device-side types and helpers shared by the kernels of libsandcrate_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sandcrate_hip.h"
+
+namespace sc {
+
+constexpr int kBlock = 256;          // 4 wave64 per workgroup
+constexpr int kMaxNbr = SC_MAX_NEIGHBORS;
+constexpr int kMaxSeg = SC_MAX_SEGMENTS;
+constexpr int kMaxBody = SC_MAX_BODIES;
+
+struct Seg {
+  double ax, ay, bx, by;
+};
+
+struct BodyK {
+  double px, py, vx, vy, omega;
+  int nseg;
+  int pad_;
+};
+
+// Everything a tick's kernels need besides the particle arrays, passed BY VALUE as a kernel
+// argument (about 2.3 KB of the 4 KB kernarg segment): uniform data is then read with scalar
+// loads, nothing has to be staged through a device buffer, and a captured launch keeps its own
+// copy.  Coefficients are live-editable in the reference (playback.py:221-226), so they are
+// never compiled in.
+struct World {
+  // coefficients (crate.py:42-57)
+  double dt, r, d, decay, pamp, ignored, level, visc, ss, tp, gx, gy;
+  // decision thresholds derived on the host, see sc_host.cpp: make_world()
+  double t_nbr;      // largest s with sqrt(s) <= d          (collision_detector.py:78-79)
+  double t_wall;     // largest s with sqrt(s) <= r * 1.2    (crate.py:229)
+  double lo, hi;     // -r, 1 + r                             (crate.py:152)
+  double touch_box;  // bounding-box reject radius for wall contact
+  double far_box;    // bounding-box radius beyond which no padded segment can be crossed
+  double ccd_skip2;  // squared step length below which `far` particles skip the crossing test
+  // cell grid: row = floor(y/d) - row0, col = floor(x/d) - col0; ring of empty cells around it
+  long long row0, col0;
+  int nrows, ncols;
+  int nseg, nbody;
+  int noise_mode;
+  int tick;
+  unsigned long long noise_key;
+  // slab decomposition (single GPU: owns every column)
+  long long own_lo, own_hi;
+  Seg seg[kMaxSeg];
+  Seg pad[2 * kMaxSeg];
+  BodyK body[kMaxBody];
+};
+
+// indices into the small device-side counter block
+enum Counter {
+  C_NS = 0,     // particles in the storage arrays at the start of the tick
+  C_NT = 1,     // live particles after removal (= entries of the sorted arrays)
+  C_FLAGS = 2,  // error bits
+  C_WREC = 3,   // wall records appended this tick
+  C_SUMC = 4,   // sum of neighbor counts (low 32 bits)
+  C_MAXC = 5,   // max neighbor count
+  C_SUMC_HI = 6,
+  C_COUNT = 8
+};
+
+enum Flag { F_OUT_OF_GRID = 1, F_NAN = 2 };
+
+// Counter-based collider noise: two uniforms in [0,1) with 32 bits each from one 64-bit hash of
+// (tick key, particle id, slot).  oracle/tick.py:counter_noise_u01 is the same function.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z ^= z >> 33;
+  z *= 0xFF51AFD7ED558CCDull;
+  z ^= z >> 33;
+  z *= 0xC4CEB9FE1A85EC53ull;
+  z ^= z >> 33;
+  return z;
+}
+
+__device__ __forceinline__ void noise_u01(uint64_t key, int id, int slot, double& ux, double& uy) {
+  uint64_t ctr = (uint64_t)(uint32_t)id * 32ull + (uint64_t)slot;
+  uint64_t h = mix64((ctr * 0x9E3779B97F4A7C15ull) ^ key);
+  ux = (double)(uint32_t)(h >> 32) * (1.0 / 4294967296.0);
+  uy = (double)(uint32_t)(h & 0xFFFFFFFFull) * (1.0 / 4294967296.0);
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_down(v, o, 64));
+  return v;
+}
+
+}  // namespace sc

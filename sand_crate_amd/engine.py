@@ -1,0 +1,166 @@
+"""`Engine`: one GPU context of libsandcrate_hip.so with NumPy in/out.
+
+This is the thinnest Python layer over the C ABI (include/sandcrate_hip.h); `Crate` (crate.py)
+builds the reference's `Crate.physics_tick()` surface on top of it.  Device state stays resident
+between ticks; nothing is copied back unless asked for.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _native as N
+
+
+@dataclass
+class StepStats:
+    particles: int
+    neighbor_slots: int
+    max_neighbors: int
+    wall_particles: int
+    flags: int
+
+
+class Engine:
+    def __init__(self, capacity: int, device: int = 0):
+        self._lib = N.load()
+        self._ctx = N._P()
+        N.check(self._lib.sc_create(int(device), int(capacity), C.byref(self._ctx)))
+        self.capacity = int(capacity)
+        self.device = int(device)
+
+    # -- lifetime
+    def close(self) -> None:
+        if self._ctx:
+            self._lib.sc_destroy(self._ctx)
+            self._ctx = N._P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle: int | None) -> None:
+        N.check(self._lib.sc_set_stream(self._ctx, N._P(stream_handle) if stream_handle else None))
+
+    # -- state
+    def upload(self, particles, velocities) -> None:
+        p, v = N.f64(particles).reshape(-1, 2), N.f64(velocities).reshape(-1, 2)
+        if p.shape != v.shape:
+            raise ValueError("particles and velocities must both be P x 2")
+        N.check(self._lib.sc_upload_state(self._ctx, N.dptr(p), N.dptr(v), len(p)))
+
+    def append(self, particles, velocities) -> None:
+        p, v = N.f64(particles).reshape(-1, 2), N.f64(velocities).reshape(-1, 2)
+        N.check(self._lib.sc_append_particles(self._ctx, N.dptr(p), N.dptr(v), len(p)))
+
+    def count(self) -> int:
+        n = C.c_int64(0)
+        N.check(self._lib.sc_count(self._ctx, C.byref(n)))
+        return n.value
+
+    def download(self, room: int | None = None):
+        """-> particles (P,2), velocities (P,2), pressure (P,), ids (P,) in particle-index order."""
+        room = self.capacity if room is None else int(room)
+        xy = np.empty((room, 2))
+        vxy = np.empty((room, 2))
+        pr = np.empty(room)
+        ids = np.empty(room, dtype=np.int64)
+        n = C.c_int64(0)
+        N.check(self._lib.sc_download_state(self._ctx, N.dptr(xy), N.dptr(vxy), N.dptr(pr), N.i64ptr(ids), room, C.byref(n)))
+        k = n.value
+        return xy[:k].copy(), vxy[:k].copy(), pr[:k].copy(), ids[:k].copy()
+
+    # -- per-tick inputs
+    def set_params(self, *, dt, particle_radius, wall_collision_decay, pressure_amplifier, ignored_pressure,
+                   collider_noise_level, viscosity, surface_smoothing, target_pressure, gravity) -> None:
+        g = np.asarray(gravity, dtype=np.float64).reshape(2)
+        p = N.Params(float(dt), float(particle_radius), float(wall_collision_decay), float(pressure_amplifier),
+                     float(ignored_pressure), float(collider_noise_level), float(viscosity), float(surface_smoothing),
+                     float(target_pressure), float(g[0]), float(g[1]))
+        N.check(self._lib.sc_set_params(self._ctx, C.byref(p)))
+
+    def set_segments(self, segments, padded, bodies) -> None:
+        """segments (S,2,2); padded (2S,2,2); bodies: iterable of (position, center_velocity, omega, n_segments)."""
+        seg = N.f64(segments).reshape(-1, 2, 2)
+        pad = N.f64(padded).reshape(-1, 2, 2)
+        if len(pad) != 2 * len(seg):
+            raise ValueError("padded must hold two segments per wall segment")
+        bodies = list(bodies)
+        arr = (N.Body * max(len(bodies), 1))()
+        for k, (pos, vel, omega, nseg) in enumerate(bodies):
+            pos = np.asarray(pos, dtype=np.float64).reshape(2)
+            vel = np.asarray(vel, dtype=np.float64).reshape(2)
+            arr[k] = N.Body(pos[0], pos[1], vel[0], vel[1], float(omega), int(nseg), 0)
+        N.check(self._lib.sc_set_segments(self._ctx, N.dptr(seg), N.dptr(pad), len(seg), arr, len(bodies)))
+
+    def set_noise_mode(self, mode: int, seed: int = 0) -> None:
+        N.check(self._lib.sc_set_noise_mode(self._ctx, int(mode), int(seed) & (2 ** 64 - 1)))
+
+    # -- the tick
+    def step_begin(self) -> None:
+        N.check(self._lib.sc_step_begin(self._ctx))
+
+    def step_stats(self) -> StepStats:
+        s = N.Stats()
+        N.check(self._lib.sc_step_stats(self._ctx, C.byref(s)))
+        return StepStats(s.particles, s.neighbor_slots, s.max_neighbors, s.wall_particles, s.flags)
+
+    def set_noise_host(self, u01) -> None:
+        u = N.f64(u01).reshape(-1, 2)
+        N.check(self._lib.sc_set_noise_host(self._ctx, N.dptr(u), len(u)))
+
+    def step_finish(self) -> None:
+        N.check(self._lib.sc_step_finish(self._ctx))
+
+    def step(self, n_ticks: int = 1) -> None:
+        N.check(self._lib.sc_step(self._ctx, int(n_ticks)))
+
+    def synchronize(self) -> None:
+        N.check(self._lib.sc_synchronize(self._ctx))
+
+    # -- parity taps (between step_begin and step_finish)
+    def download_sort(self):
+        room = self.capacity
+        rows = np.empty(room, dtype=np.int64)
+        ids = np.empty(room, dtype=np.int64)
+        n = C.c_int64(0)
+        N.check(self._lib.sc_download_sort(self._ctx, N.i64ptr(rows), N.i64ptr(ids), room, C.byref(n)))
+        return rows[:n.value].copy(), ids[:n.value].copy()
+
+    def download_neighbors(self):
+        """-> ids (P,), counts (P,), neighbor ids (P,20), fixed positions (P,2); one row per sorted slot."""
+        room = self.capacity
+        ids = np.empty(room, dtype=np.int64)
+        cnt = np.empty(room, dtype=np.int32)
+        nb = np.empty((room, N.MAX_NEIGHBORS), dtype=np.int64)
+        fx = np.empty((room, 2))
+        n = C.c_int64(0)
+        N.check(self._lib.sc_download_neighbors(self._ctx, N.i64ptr(ids), N.i32ptr(cnt), N.i64ptr(nb), N.dptr(fx), room,
+                                                C.byref(n)))
+        k = n.value
+        return ids[:k].copy(), cnt[:k].copy(), nb[:k].copy(), fx[:k].copy()
+
+    def download_normals(self):
+        room = self.capacity
+        s = np.empty((room, 2))
+        n = C.c_int64(0)
+        N.check(self._lib.sc_download_normals(self._ctx, N.dptr(s), room, C.byref(n)))
+        return s[:n.value].copy()
+
+    # -- timing
+    def enable_timing(self, on: bool = True) -> None:
+        N.check(self._lib.sc_enable_timing(self._ctx, 1 if on else 0))
+
+    def reset_timing(self) -> None:
+        N.check(self._lib.sc_reset_timing(self._ctx))
+
+    def timing(self) -> dict[str, tuple[float, int]]:
+        """-> {kernel name: (total ms, launches)} since reset_timing()."""
+        ms = np.zeros(N.NUM_KERNELS)
+        cnt = np.zeros(N.NUM_KERNELS, dtype=np.int64)
+        N.check(self._lib.sc_get_timing(self._ctx, N.dptr(ms), N.i64ptr(cnt)))
+        return {self._lib.sc_kernel_name(k).decode(): (float(ms[k]), int(cnt[k])) for k in range(N.NUM_KERNELS)}

@@ -83,3 +83,16 @@ def test_scene_trajectory_matches_reference(scene):
             np.testing.assert_allclose(crate.particles, g[f"particles_t{t}"], rtol=RTOL, atol=1e-9)
             np.testing.assert_allclose(crate.particle_velocities, g[f"velocities_t{t}"], rtol=RTOL, atol=1e-7)
             np.testing.assert_allclose(crate.particles_pressure, g[f"pressure_t{t}"], rtol=RTOL, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["tick_synth512_cup", "tick_stirring_cup_t300", "tick_wave_machine_t100"])
+def test_loop_structured_tick_matches_reference(name):
+    """oracle.tick_loops (what bench.py times as the reference's NumPy path) is the same function."""
+    from oracle.tick_loops import tick_loops
+    g = load_golden(name)
+    eta = g["eta_u01"]
+    out = tick_loops(g["in_particles"], g["in_velocities"], g["segments"], bodies_of(g), coef_of(g),
+                     eta_source=lambda total: eta[:total])
+    close(out["pressure"], g["out_pressure"])
+    close(out["velocities"], g["out_velocities"])
+    close(out["particles"], g["out_particles"])
