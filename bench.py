@@ -121,23 +121,28 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     n_total = args.particles * world
 
+    wc, d = world_for(n_total)
+    p, v = synthetic_state(n_total)
     if world > 1:
         import torch.distributed as dist
         from sand_crate_amd.slab import SlabCrate
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        wc, d = world_for(n_total)
-        p, v = synthetic_state(n_total)
-        sim = SlabCrate(wc, p, v, device=local_rank, noise=args.noise, noise_seed=1)
         barrier = dist.barrier
     else:
-        wc, d = world_for(n_total)
-        p, v = synthetic_state(n_total)
-        sim = sc.Crate(wc, device=local_rank, noise=args.noise, noise_seed=1, capacity=n_total + 1024)
-        sim.particles = p
-        sim.particle_velocities = v
-
         def barrier():
             return None
+
+    def make_sim():
+        import copy
+        w = copy.deepcopy(wc)
+        if world > 1:
+            return SlabCrate(w, p, v, device=local_rank, noise=args.noise, noise_seed=1)
+        s = sc.Crate(w, device=local_rank, noise=args.noise, noise_seed=1, capacity=n_total + 1024)
+        s.particles = p
+        s.particle_velocities = v
+        return s
+
+    sim = make_sim()
 
     def run(k):
         sim.run(k)
@@ -158,11 +163,16 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
 
-    # ---- kernel durations: the same K steps again, every launch bracketed by two HIP events on the
-    # stream the kernels run on.  Kept out of the timed region because the 14 event records per tick
+    # ---- kernel durations: the same ticks replayed from the same initial state, every launch
+    # bracketed by two HIP events on the stream the kernels run on.  Kept out of the timed region because the 14 event records per tick
     # cost ~15 % wall time at this size (measured); kernel durations themselves are unaffected.
     timing = {}
+    n_live = sim.particle_count if world == 1 else sim.global_particle_count()
     if not args.no_kernel_events:
+        sim = make_sim()  # same initial state, same ticks as the timed region
+        eng = sim.engine
+        run(args.warmup)
+        sim.synchronize()
         eng.reset_timing()
         eng.enable_timing(True)
         run(args.steps)
@@ -175,8 +185,6 @@ def main() -> None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    n_live = sim.particle_count if world == 1 else sim.global_particle_count()
-
     if rank == 0 and args.no_kernel_events:
         print(json.dumps({"metric": "particle-steps/sec", "value": n_total * args.steps / elapsed,
                           "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -197,7 +205,7 @@ def main() -> None:
         roofline = {
             "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS, 5), "traffic": None,
-            "measured_over": f"{args.steps} further steps right after the timed region, HIP events around every launch",
+            "measured_over": f"a replay of the same {args.warmup}+{args.steps} ticks from the same initial state right after the timed region, HIP events around every launch",
             "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * per_gpu,
             "avg_launch_us": kernels[dom]["avg_us"],
             "force_pair": {"kernels": "density + force_integrate", "bytes_per_particle": FORCE_BYTES,

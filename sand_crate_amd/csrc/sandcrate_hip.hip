@@ -80,6 +80,8 @@ struct sc_ctx {
   double *x[2] = {}, *y[2] = {}, *vx[2] = {}, *vy[2] = {};
   int* id[2] = {};
   int *cellS = nullptr, *wslotS = nullptr, *cellT = nullptr, *wslotT = nullptr, *perm = nullptr;
+  double* keyX = nullptr;
+  int* keyId = nullptr;
   int *cellCount = nullptr, *cellStart = nullptr, *blockSums = nullptr;
   int64_t cellAlloc = 0;
   double* wrec = nullptr;
@@ -254,6 +256,7 @@ int make_world(sc_ctx* c) {
     w.row0 = w.col0 = cmin - 1;
     w.nrows = w.ncols = (int)(cmax - cmin + 1) + 2;
   }
+  w.inv_d = 1.0 / w.d;
   w.nseg = c->nseg;
   w.nbody = c->nbody;
   std::memcpy(w.seg, c->seg, sizeof w.seg);
@@ -354,6 +357,8 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
   if (e == hipSuccess) e = dalloc(&c->cellT, n);
   if (e == hipSuccess) e = dalloc(&c->wslotT, n);
   if (e == hipSuccess) e = dalloc(&c->perm, n);
+  if (e == hipSuccess) e = dalloc(&c->keyX, n);
+  if (e == hipSuccess) e = dalloc(&c->keyId, n);
   if (e == hipSuccess) e = dalloc(&c->wrec, 5 * n);
   if (e == hipSuccess) e = dalloc(&c->nbr, (size_t)kMaxNbr * n);
   if (e == hipSuccess) e = dalloc(&c->cnt, n);
@@ -382,7 +387,7 @@ int sc_destroy(sc_ctx* c) {
     (void)hipFree(c->vy[s]);
     (void)hipFree(c->id[s]);
   }
-  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->cellCount, c->cellStart, c->blockSums, c->wrec,
+  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->cellCount, c->cellStart, c->blockSums, c->wrec,
                   c->nbr, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
                   c->stage_xy, c->stage_vxy};
   for (void* p : ptrs)
@@ -485,7 +490,6 @@ int sc_step_begin(sc_ctx* c) {
   const World& w = c->w;
   int grid = grid_for(c->upper);
   int cap = (int)c->cap;
-  HIPCHK(hipMemsetAsync(c->counters + C_WREC, 0, 4 * sizeof(int), c->stream));  // WREC, SUMC, MAXC, SUMC_HI
   {
     Bracket br(c, K_WALL_BIN);
     hipLaunchKernelGGL(k_wall_bin, dim3(grid), dim3(kBlock), 0, c->stream, w, c->counters, c->x[0], c->y[0], c->cellS,
@@ -498,18 +502,19 @@ int sc_step_begin(sc_ctx* c) {
   }
   {
     Bracket br(c, K_SCATTER);
-    hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->cellS, c->cellStart,
-                       c->cellCount, c->perm);
+    hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->cellS, c->x[0],
+                       c->id[0], c->cellStart, c->cellCount, c->perm, c->keyX, c->keyId);
   }
   {
     Bracket br(c, K_REORDER);
-    hipLaunchKernelGGL(k_reorder, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->perm, c->cellS, c->cellStart,
-                       c->wslotS, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], c->x[1], c->y[1], c->vx[1], c->vy[1],
-                       c->id[1], c->cellT, c->wslotT);
+    hipLaunchKernelGGL(k_reorder, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->perm, c->keyX, c->keyId,
+                       c->cellS, c->cellStart, c->wslotS, c->y[0], c->vx[0], c->vy[0], c->x[1], c->y[1], c->vx[1],
+                       c->vy[1], c->id[1], c->cellT, c->wslotT);
   }
   {
     Bracket br(c, K_NEIGHBORS);
-    hipLaunchKernelGGL(k_neighbors, dim3(grid), dim3(kBlock), 0, c->stream, w, c->counters, c->x[1], c->y[1], c->cellT,
+    int ngrid = (int)std::max<int64_t>(1, (c->upper + kNbrPerBlock - 1) / kNbrPerBlock);
+    hipLaunchKernelGGL(k_neighbors, dim3(ngrid), dim3(kBlock), 0, c->stream, w, c->counters, c->x[1], c->y[1], c->cellT,
                        c->cellStart, c->nbr, c->cnt, cap);
   }
   if (c->noise_mode == SC_NOISE_HOST && c->next_id > 0) {
@@ -530,6 +535,7 @@ int sc_step_begin(sc_ctx* c) {
 int sc_step_stats(sc_ctx* c, sc_stats* out) {
   if (!c || !out) return fail(SC_ERR_ARG, "null argument");
   if (!c->in_step) return fail(SC_ERR_STATE, "sc_step_stats needs sc_step_begin first");
+  hipLaunchKernelGGL(k_count_stats, dim3(1), dim3(kBlock), 0, c->stream, c->counters, c->cnt);
   int h[C_COUNT];
   int rc = read_counters(c, h);
   if (rc) return rc;

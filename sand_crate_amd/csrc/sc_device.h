@@ -30,6 +30,7 @@ struct BodyK {
 struct World {
   // coefficients (crate.py:42-57)
   double dt, r, d, decay, pamp, ignored, level, visc, ss, tp, gx, gy;
+  double inv_d;      // 1/d, for the float-tolerance math only (never for a decision)
   // decision thresholds derived on the host, see sc_host.cpp: make_world()
   double t_nbr;      // largest s with sqrt(s) <= d          (collision_detector.py:78-79)
   double t_wall;     // largest s with sqrt(s) <= r * 1.2    (crate.py:229)
@@ -81,6 +82,34 @@ __device__ __forceinline__ void noise_u01(uint64_t key, int id, int slot, double
   uint64_t h = mix64((ctr * 0x9E3779B97F4A7C15ull) ^ key);
   ux = (double)(uint32_t)(h >> 32) * (1.0 / 4294967296.0);
   uy = (double)(uint32_t)(h & 0xFFFFFFFFull) * (1.0 / 4294967296.0);
+}
+
+// Runs of equal keys among the lanes of a wave.  Storage order is the previous tick's sorted order,
+// so consecutive lanes mostly fall into the same cell: one atomic per run instead of one per
+// particle takes the same-address serialisation out of the cell counters (a cell that collects
+// thousands of particles is hit by n/64 atomics instead of n).
+struct LaneRun {
+  int head;  // lane index of the first lane of this lane's run
+  int len;   // number of lanes in the run
+  bool is_head;
+};
+
+__device__ __forceinline__ LaneRun lane_run(int key) {
+  const int lane = threadIdx.x & 63;
+  int prev = __shfl_up(key, 1, 64);
+  bool is_head = lane == 0 || key != prev;
+  unsigned long long heads = __ballot(is_head);  // every lane of the wave must call this
+  unsigned long long below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+  int head = 63 - __clzll(below);
+  unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+  int next = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+  // lanes past the end of the data are given distinct negative keys by the callers, so `next`
+  // never merges them into a real run
+  LaneRun r;
+  r.head = head;
+  r.len = next - head;
+  r.is_head = is_head;
+  return r;
 }
 
 __device__ __forceinline__ int wave_sum(int v) {

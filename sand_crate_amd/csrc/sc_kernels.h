@@ -10,6 +10,18 @@ namespace sc {
 // np.clip(t, 0, 1): NaN passes through, like NumPy's minimum/maximum.
 __device__ __forceinline__ double clip01(double t) { return t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t); }
 
+// Closest point of segment s to (px,py) and the squared distance to it, evaluated exactly like
+// points_to_segments_distance (geometry_utils.py:26-38): separate multiplies and adds, IEEE divide.
+__device__ __forceinline__ double closest_on_segment(const Seg& s, double px, double py, double& cx, double& cy) {
+  double abx = s.bx - s.ax, aby = s.by - s.ay;
+  double apx = px - s.ax, apy = py - s.ay;
+  double t = clip01((apx * abx + apy * aby) / (abx * abx + aby * aby));
+  cx = abx * t + s.ax;
+  cy = aby * t + s.ay;
+  double dx = cx - px, dy = cy - py;
+  return dx * dx + dy * dy;
+}
+
 // ------------------------------------------------------------------------------------------
 // K0  append: crate.py:138-147 (create_new_particles).  Host arrays are P x 2 interleaved.
 // ------------------------------------------------------------------------------------------
@@ -42,17 +54,13 @@ __global__ void k_bump(int* counters, int m, int reset) { counters[C_NS] = (rese
 // A wall record is (sum_k u_k, sum_k vel_k, V): all that apply_pressure (:295-307) and
 // apply_wall_bounce (:245-259) need later.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_wall_bin(World w, int* __restrict__ counters, double* __restrict__ x,
-                                                     double* __restrict__ y, int* __restrict__ cellS,
-                                                     int* __restrict__ wslotS, int* __restrict__ cellCount,
-                                                     double* __restrict__ wrec) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= counters[C_NS]) return;
+// The per-particle part of K1; returns the particle's cell or -1 (removed / beyond the data).
+__device__ __forceinline__ int wall_and_cell(const World& w, int i, int* __restrict__ counters, double* __restrict__ x,
+                                             double* __restrict__ y, int* __restrict__ wslotS,
+                                             double* __restrict__ wrec) {
+  if (i >= counters[C_NS]) return -1;
   double px = x[i], py = y[i];
-  if (px < w.lo || px > w.hi || py < w.lo || py > w.hi) {  // crate.py:152
-    cellS[i] = -1;
-    return;
-  }
+  if (px < w.lo || px > w.hi || py < w.lo || py > w.hi) return -1;  // crate.py:152
   // bounding-box reject (exact-safe: the boxes are inflated far beyond rounding error)
   unsigned cand = 0;
   bool far = true;
@@ -65,54 +73,51 @@ __global__ void __launch_bounds__(kBlock) k_wall_bin(World w, int* __restrict__ 
   }
   int wslot = far ? -1 : -2;
   if (cand) {
-    double cpx[kMaxSeg], cpy[kMaxSeg], ux[kMaxSeg], uy[kMaxSeg];
+    // pass 1: which segments touch (geometry_utils.py:26-38 with the reference's operation order)
     unsigned touch = 0;
-    int V = 0;
     for (int k = 0; k < w.nseg; ++k) {
       if (!(cand >> k & 1u)) continue;
-      Seg s = w.seg[k];
-      // geometry_utils.py:26-38, same operation order
-      double abx = s.bx - s.ax, aby = s.by - s.ay;
-      double apx = px - s.ax, apy = py - s.ay;
-      double t = (apx * abx + apy * aby) / (abx * abx + aby * aby);
-      t = clip01(t);
-      double cx = abx * t + s.ax, cy = aby * t + s.ay;
-      double dx = cx - px, dy = cy - py;
-      double s2 = dx * dx + dy * dy;
-      if (s2 <= w.t_wall) {  // == (sqrt(s2) <= r * 1.2), crate.py:229
-        cpx[V] = cx;
-        cpy[V] = cy;
-        ux[V] = (px - cx) * 2;  // crate.py:234
-        uy[V] = (py - cy) * 2;
-        touch |= 1u << k;
-        ++V;
-      }
+      double cx, cy;
+      if (closest_on_segment(w.seg[k], px, py, cx, cy) <= w.t_wall) touch |= 1u << k;  // crate.py:229
     }
-    if (V > 0) {
-      // crate.py:73-85: every body with n_b touching segments overwrites slots [0, n_b)
-      double velx[kMaxSeg], vely[kMaxSeg];
-      for (int k = 0; k < V; ++k) velx[k] = vely[k] = 0.0;
-      int seg0 = 0;
-      for (int b = 0; b < w.nbody; ++b) {
-        BodyK bd = w.body[b];
-        unsigned mask = (bd.nseg >= 32 ? 0xFFFFFFFFu : ((1u << bd.nseg) - 1u)) << seg0;
-        int nb = __popc(touch & mask);
-        seg0 += bd.nseg;
-        for (int k = 0; k < nb; ++k) {
-          velx[k] = bd.vx + (cpy[k] - bd.py) * bd.omega;
-          vely[k] = bd.vy + (-(cpx[k] - bd.px)) * bd.omega;
+    if (touch) {
+      // crate.py:73-85: a body with n_b touching segments overwrites contact slots [0, n_b) -- of ALL
+      // contacts, not of its own -- so slot q ends up with the velocity law of the LAST body whose
+      // n_b exceeds q, evaluated at contact point q; slots beyond every n_b keep velocity 0.
+      int nbv[kMaxBody];
+      {
+        int seg0 = 0;
+        for (int b = 0; b < w.nbody; ++b) {
+          int ns = w.body[b].nseg;
+          unsigned mask = (ns >= 32 ? 0xFFFFFFFFu : ((1u << ns) - 1u)) << seg0;
+          nbv[b] = __popc(touch & mask);
+          seg0 += ns;
         }
       }
       double Ux = 0, Uy = 0, Cx = 0, Cy = 0, fx = 0, fy = 0;
-      for (int k = 0; k < V; ++k) {
-        Ux += ux[k];
-        Uy += uy[k];
-        Cx += velx[k];
-        Cy += vely[k];
-        double rel = w.r / sqrt(ux[k] * ux[k] + uy[k] * uy[k]);  // crate.py:206-208
+      int q = 0;
+      for (int k = 0; k < w.nseg; ++k) {
+        if (!(touch >> k & 1u)) continue;
+        double cx, cy;
+        closest_on_segment(w.seg[k], px, py, cx, cy);
+        double ukx = (px - cx) * 2, uky = (py - cy) * 2;  // crate.py:234
+        double vkx = 0.0, vky = 0.0;
+        for (int b = 0; b < w.nbody; ++b) {
+          if (nbv[b] > q) {
+            BodyK bd = w.body[b];
+            vkx = bd.vx + (cy - bd.py) * bd.omega;  // rigid_body.py:28-34
+            vky = bd.vy + (-(cx - bd.px)) * bd.omega;
+          }
+        }
+        Ux += ukx;
+        Uy += uky;
+        Cx += vkx;
+        Cy += vky;
+        double rel = w.r / sqrt(ukx * ukx + uky * uky);  // crate.py:206-208
         if (rel < 0.5) rel = 0.5;
-        fx += ux[k] * (rel - 0.5);
-        fy += uy[k] * (rel - 0.5);
+        fx += ukx * (rel - 0.5);
+        fy += uky * (rel - 0.5);
+        ++q;
       }
       px += fx;  // crate.py:211
       py += fy;
@@ -124,25 +129,34 @@ __global__ void __launch_bounds__(kBlock) k_wall_bin(World w, int* __restrict__ 
       rec[1] = Uy;
       rec[2] = Cx;
       rec[3] = Cy;
-      rec[4] = (double)V;
+      rec[4] = (double)q;
     }
   }
   if (!(px == px) || !(py == py)) {  // crate.py:206: distance 0 to a wall gives NaN
     atomicOr(&counters[C_FLAGS], F_NAN);
-    cellS[i] = -1;
-    return;
+    return -1;
   }
   double fr = floor(py / w.d), fc = floor(px / w.d);  // collision_detector.py:126
   long long lr = (long long)fr - w.row0, lc = (long long)fc - w.col0;
   if (!(fabs(fr) < 9e15) || !(fabs(fc) < 9e15) || lr < 1 || lr > w.nrows - 2 || lc < 1 || lc > w.ncols - 2) {
     atomicOr(&counters[C_FLAGS], F_OUT_OF_GRID);
-    cellS[i] = -1;
-    return;
+    return -1;
   }
-  int c = (int)lr * w.ncols + (int)lc;
-  cellS[i] = c;
   wslotS[i] = wslot;
-  atomicAdd(&cellCount[c], 1);
+  return (int)lr * w.ncols + (int)lc;
+}
+
+
+__global__ void __launch_bounds__(kBlock) k_wall_bin(World w, int* __restrict__ counters, double* __restrict__ x,
+                                                     double* __restrict__ y, int* __restrict__ cellS,
+                                                     int* __restrict__ wslotS, int* __restrict__ cellCount,
+                                                     double* __restrict__ wrec) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int c = wall_and_cell(w, i, counters, x, y, wslotS, wrec);
+  if (i < counters[C_NS]) cellS[i] = c;
+  // one atomic per run of equal cells in the wave; lanes without a cell get distinct negative keys
+  LaneRun run = lane_run(c >= 0 ? c : -1 - (int)(threadIdx.x & 63));
+  if (run.is_head && c >= 0) atomicAdd(&cellCount[c], run.len);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -207,51 +221,70 @@ __global__ void __launch_bounds__(kBlock) k_scan_fix(int* __restrict__ out, int 
 // ------------------------------------------------------------------------------------------
 // K3  scatter: a slot inside the particle's cell bucket, in arrival order.  The returning
 // atomic counts the bucket back down to zero, so cellCount needs no clearing for the next tick.
+// The bucket slot receives the sort key (x) and the particle's storage index, so that K4 ranks
+// over CONTIGUOUS keys instead of chasing perm -> x.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ counters, const int* __restrict__ cellS,
+                                                    const double* __restrict__ xS, const int* __restrict__ idS,
                                                     const int* __restrict__ cellStart, int* __restrict__ cellCount,
-                                                    int* __restrict__ perm) {
+                                                    int* __restrict__ perm, double* __restrict__ keyX,
+                                                    int* __restrict__ keyId) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= counters[C_NS]) return;
-  int c = cellS[i];
+  int c = i < counters[C_NS] ? cellS[i] : -1;
+  const int lane = threadIdx.x & 63;
+  LaneRun run = lane_run(c >= 0 ? c : -1 - lane);
+  int base = 0;
+  if (run.is_head && c >= 0) base = cellStart[c] + atomicSub(&cellCount[c], run.len) - run.len;
+  base = __shfl(base, run.head, 64);
   if (c < 0) return;
-  int pos = cellStart[c] + atomicSub(&cellCount[c], 1) - 1;
+  int pos = base + (lane - run.head);
   perm[pos] = i;
+  keyX[pos] = xS[i];
+  keyId[pos] = idS[i];
 }
 
 // ------------------------------------------------------------------------------------------
 // K4  reorder: final slot = bucket start + rank of (x, id) inside the bucket, which makes the
 // whole array sorted by (row, x, id) = np.lexsort((x, y_floored)) with its stable tie-break
-// (collision_detector.py:127).  Moves the particle's state to the sorted arrays.
+// (collision_detector.py:127).  Moves the particle's state to the sorted arrays.  Keys and ids
+// of a bucket are contiguous, so even a bucket of thousands of exact-x ties (particles stopped
+// on a wall by the continuous-collision fix) ranks from cached, coalesced reads.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-    k_reorder(const int* __restrict__ counters, const int* __restrict__ perm, const int* __restrict__ cellS,
-              const int* __restrict__ cellStart, const int* __restrict__ wslotS, const double* __restrict__ xS,
-              const double* __restrict__ yS, const double* __restrict__ vxS, const double* __restrict__ vyS,
-              const int* __restrict__ idS, double* __restrict__ xT, double* __restrict__ yT, double* __restrict__ vxT,
-              double* __restrict__ vyT, int* __restrict__ idT, int* __restrict__ cellT, int* __restrict__ wslotT) {
+    k_reorder(const int* __restrict__ counters, const int* __restrict__ perm, const double* __restrict__ keyX,
+              const int* __restrict__ keyId, const int* __restrict__ cellS, const int* __restrict__ cellStart,
+              const int* __restrict__ wslotS, const double* __restrict__ yS, const double* __restrict__ vxS,
+              const double* __restrict__ vyS, double* __restrict__ xT, double* __restrict__ yT,
+              double* __restrict__ vxT, double* __restrict__ vyT, int* __restrict__ idT, int* __restrict__ cellT,
+              int* __restrict__ wslotT) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= counters[C_NT]) return;
   int i = perm[s];
+  double xi = keyX[s];
+  int idi = keyId[s];
   int c = cellS[i];
-  double xi = xS[i];
-  int idi = idS[i];
+  double yi = yS[i], vxi = vxS[i], vyi = vyS[i];
+  int wsi = wslotS[i];
   int b = cellStart[c], e = cellStart[c + 1];
   int rank = 0;
-  for (int t = b; t < e; ++t) {
-    int j = perm[t];
-    double xj = xS[j];
-    int idj = idS[j];
-    rank += (xj < xi) || (xj == xi && idj < idi);
+  for (int t = b; t < e; t += 4) {  // four keys in flight per round trip
+    double k0 = keyX[t], k1 = t + 1 < e ? keyX[t + 1] : xi, k2 = t + 2 < e ? keyX[t + 2] : xi,
+           k3 = t + 3 < e ? keyX[t + 3] : xi;
+    int d0 = keyId[t], d1 = t + 1 < e ? keyId[t + 1] : idi, d2 = t + 2 < e ? keyId[t + 2] : idi,
+        d3 = t + 3 < e ? keyId[t + 3] : idi;
+    rank += (k0 < xi) || (k0 == xi && d0 < idi);
+    rank += (k1 < xi) || (k1 == xi && d1 < idi);
+    rank += (k2 < xi) || (k2 == xi && d2 < idi);
+    rank += (k3 < xi) || (k3 == xi && d3 < idi);
   }
   int dst = b + rank;
   xT[dst] = xi;
-  yT[dst] = yS[i];
-  vxT[dst] = vxS[i];
-  vyT[dst] = vyS[i];
+  yT[dst] = yi;
+  vxT[dst] = vxi;
+  vyT[dst] = vyi;
   idT[dst] = idi;
   cellT[dst] = c;
-  wslotT[dst] = wslotS[i];
+  wslotT[dst] = wsi;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -259,60 +292,124 @@ __global__ void __launch_bounds__(kBlock)
 //   [same row, to the right, x ascending] [row+1, x ascending]
 //   [same row, to the left, x descending] [row-1, x descending], cut at 20.
 // In the (row, x, id)-sorted array each of the three rows' candidates (columns c-1..c+1) is one
-// contiguous range.  The forward predicates are the reference's own (:106-119, :75-80); a
-// reverse edge j->i exists exactly when i is a forward candidate of j (:85-88).
-// Lists are written slot-major (nbr[s*cap + i]) so that lanes store/load consecutive words.
+// contiguous range, so the canonical candidate sequence of particle i is four index runs:
+//   i+1 .. e0-1 | b1 .. e1-1 | i-1 .. b0 (down) | em-1 .. bm (down).
+// Sixteen lanes share one particle: each tests one candidate of the current 16-wide chunk, the
+// wave ballot of the predicate is cut into the group's 16 bits, and the popcount of the lower bits
+// is the lane's slot in the list (prefix-sum compaction); the running total stops the scan at 20.
+// The forward predicates are the reference's own (:106-119, :75-80); a reverse edge j->i exists
+// exactly when i is a forward candidate of j (:85-88).  A workgroup handles 64 particles, keeps
+// their lists in LDS and writes them slot-major (nbr[s*cap + i]) with coalesced stores.
 // ------------------------------------------------------------------------------------------
+constexpr int kNbrPerBlock = 64;
+
 __global__ void __launch_bounds__(kBlock)
     k_neighbors(World w, int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
                 const int* __restrict__ cell, const int* __restrict__ cellStart, int* __restrict__ nbr,
                 unsigned char* __restrict__ cnt, int cap) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  int n = counters[C_NT];
-  int count = 0;
-  if (i < n) {
-    int c = cell[i];
-    double xi = x[i], yi = y[i];
-    double xhi = xi + w.d, xlo = xi - w.d;
-    int e0 = cellStart[c + 2];
-    for (int j = i + 1; j < e0 && count < kMaxNbr; ++j) {  // same strip, after i (:106-109)
-      double xj = x[j];
-      if (xj > xhi) break;
-      double dx = xj - xi, dy = y[j] - yi;
-      if (dx * dx + dy * dy <= w.t_nbr) nbr[(size_t)count++ * cap + i] = j;
-    }
-    int b1 = cellStart[c + w.ncols - 1], e1 = cellStart[c + w.ncols + 2];
-    for (int j = b1; j < e1 && count < kMaxNbr; ++j) {  // next strip (:112-119)
-      double xj = x[j];
-      if (xj > xhi) break;
-      if (xj >= xlo) {
-        double dx = xj - xi, dy = y[j] - yi;
-        if (dx * dx + dy * dy <= w.t_nbr) nbr[(size_t)count++ * cap + i] = j;
+  __shared__ int list[kMaxNbr][kNbrPerBlock + 1];
+  __shared__ int counts[kNbrPerBlock];
+  const int n = counters[C_NT];
+  const int g = threadIdx.x & 15;          // lane inside the group
+  const int grp = threadIdx.x >> 4;        // group inside the workgroup (0..15)
+  const int shift = (threadIdx.x & 63) & ~15;  // where the group's bits sit in the wave ballot
+  const int i0 = blockIdx.x * kNbrPerBlock;
+  for (int round = 0; round < kNbrPerBlock / 16; ++round) {
+    const int local = round * 16 + grp;
+    const int i = i0 + local;
+    int base = 0;
+    if (i < n) {  // uniform inside the group
+      const int c = cell[i];
+      const double xi = x[i], yi = y[i];
+      const double xhi = xi + w.d, xlo = xi - w.d;
+      const int e0 = cellStart[c + 2], b0 = cellStart[c - 1];
+      const int b1 = cellStart[c + w.ncols - 1], e1 = cellStart[c + w.ncols + 2];
+      const int bm = cellStart[c - w.ncols - 1], em = cellStart[c - w.ncols + 2];
+      const int n0 = e0 - (i + 1), n1 = e1 - b1, n2 = i - b0, n3 = em - bm;
+      const int total = n0 + n1 + n2 + n3;
+      for (int v0 = 0; v0 < total && base < kMaxNbr; v0 += 16) {
+        int v = v0 + g;
+        bool ok = false;
+        int j = 0;
+        if (v < total) {
+          int type;
+          if (v < n0) {
+            j = i + 1 + v;
+            type = 0;
+          } else if (v < n0 + n1) {
+            j = b1 + (v - n0);
+            type = 1;
+          } else if (v < n0 + n1 + n2) {
+            j = i - 1 - (v - n0 - n1);
+            type = 2;
+          } else {
+            j = em - 1 - (v - n0 - n1 - n2);
+            type = 3;
+          }
+          double xj = x[j], yj = y[j];
+          bool win;
+          if (type == 0) {
+            win = xj <= xhi;                       // searchsorted(strip_x, x_i + d, "right")      :106
+          } else if (type == 1) {
+            win = xj >= xlo && xj <= xhi;          // next strip window                           :112-113
+          } else if (type == 2) {
+            win = xi <= xj + w.d;                  // i is in j's same-strip window
+          } else {
+            win = xi >= xj - w.d && xi <= xj + w.d;  // i is in j's next-strip window
+          }
+          double dx = xj - xi, dy = yj - yi;
+          ok = win && (dx * dx + dy * dy <= w.t_nbr);  // norm(p_j - p_i) <= d                      :78-79
+        }
+        unsigned long long ballot = __ballot(ok);
+        unsigned mask = (unsigned)(ballot >> shift) & 0xFFFFu;
+        int slot = base + __popc(mask & ((1u << g) - 1u));
+        if (ok && slot < kMaxNbr) list[slot][local] = j;
+        base += __popc(mask);
       }
+      if (base > kMaxNbr) base = kMaxNbr;
     }
-    int b0 = cellStart[c - 1];
-    for (int j = i - 1; j >= b0 && count < kMaxNbr; --j) {  // reverse edges from the same strip
-      double xj = x[j];
-      if (!(xi <= xj + w.d)) break;
-      double dx = xj - xi, dy = y[j] - yi;
-      if (dx * dx + dy * dy <= w.t_nbr) nbr[(size_t)count++ * cap + i] = j;
-    }
-    int bm = cellStart[c - w.ncols - 1], em = cellStart[c - w.ncols + 2];
-    for (int j = em - 1; j >= bm && count < kMaxNbr; --j) {  // reverse edges from the previous strip
-      double xj = x[j];
-      if (!(xi <= xj + w.d)) break;
-      if (xi >= xj - w.d) {
-        double dx = xj - xi, dy = y[j] - yi;
-        if (dx * dx + dy * dy <= w.t_nbr) nbr[(size_t)count++ * cap + i] = j;
-      }
-    }
-    cnt[i] = (unsigned char)count;
+    if (g == 0) counts[local] = base;
   }
-  int s = wave_sum(count), m = wave_max(count);
-  if ((threadIdx.x & 63) == 0 && s) {
-    unsigned old = atomicAdd((unsigned*)&counters[C_SUMC], (unsigned)s);
-    if (old + (unsigned)s < old) atomicAdd(&counters[C_SUMC_HI], 1);
-    atomicMax(&counters[C_MAXC], m);
+  __syncthreads();
+  // coalesced write-out: thread t handles particle (t & 63), slots (t >> 6), +4, +8, ...
+  const int pl = threadIdx.x & 63;
+  const int ip = i0 + pl;
+  const int cp = ip < n ? counts[pl] : 0;
+  if (ip < n) {
+    for (int s = threadIdx.x >> 6; s < cp; s += kBlock / 64) nbr[(size_t)s * cap + ip] = list[s][pl];
+    if (threadIdx.x < 64) cnt[ip] = (unsigned char)cp;
+  }
+}
+
+// Sum and maximum of the neighbor counts, on demand (sc_step_stats).  Kept out of K5: one atomic
+// per workgroup on a single address serialises at ~12 ns each and dominated that kernel.
+__global__ void __launch_bounds__(kBlock) k_count_stats(int* __restrict__ counters, const unsigned char* __restrict__ cnt) {
+  __shared__ int ssum[kBlock / 64], smax[kBlock / 64];
+  int n = counters[C_NT];
+  long long sum = 0;
+  int mx = 0;
+  for (int i = threadIdx.x; i < n; i += kBlock) {
+    int c = cnt[i];
+    sum += c;
+    mx = max(mx, c);
+  }
+  // counts are <= 20, so a lane's partial sum fits 32 bits for n < 1e8
+  int s32 = wave_sum((int)sum), m32 = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) {
+    ssum[threadIdx.x >> 6] = s32;
+    smax[threadIdx.x >> 6] = m32;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long tot = 0;
+    int m = 0;
+    for (int k = 0; k < kBlock / 64; ++k) {
+      tot += (unsigned)ssum[k];
+      m = max(m, smax[k]);
+    }
+    counters[C_SUMC] = (int)(unsigned)(tot & 0xFFFFFFFFull);
+    counters[C_SUMC_HI] = (int)(tot >> 32);
+    counters[C_MAXC] = m;
   }
 }
 
@@ -366,8 +463,9 @@ __global__ void __launch_bounds__(kBlock)
     collider_noise<NOISE>(w, idi, s, eta, off, ex, ey);
     double rx = xi - (x[j] + ex), ry = yi - (y[j] + ey);  // crate.py:167-171
     double dist = sqrt(rx * rx + ry * ry);
-    double nx = rx / dist, ny = ry / dist;                 // crate.py:174
-    double ov = 1 - clip01(dist / w.d);                    // crate.py:270
+    double rinv = 1.0 / dist;
+    double nx = rx * rinv, ny = ry * rinv;                 // crate.py:174
+    double ov = 1 - clip01(dist * w.inv_d);                // crate.py:270
     sumw += ov;
     double t = (1 - ov) * ov;                              // crate.py:342
     ax += t * nx;
@@ -396,7 +494,13 @@ __global__ void __launch_bounds__(kBlock)
             int* __restrict__ ido) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int n = counters[C_NT];
-  if (i == 0) counters[C_NS] = n;  // the storage arrays now hold the n live particles
+  if (i == 0) {
+    counters[C_NS] = n;  // the storage arrays now hold the n live particles
+    counters[C_WREC] = 0;  // per-tick counters start the next tick at zero (read by sc_step_stats
+    counters[C_SUMC] = 0;  // between sc_step_begin and sc_step_finish, i.e. before this kernel)
+    counters[C_SUMC_HI] = 0;
+    counters[C_MAXC] = 0;
+  }
   if (i >= n) return;
   int C = cnt[i];
   double xi = x[i], yi = y[i];
@@ -410,8 +514,8 @@ __global__ void __launch_bounds__(kBlock)
     double ex, ey;
     collider_noise<NOISE>(w, idi, s, eta, off, ex, ey);
     double rx = xi - (x[j] + ex), ry = yi - (y[j] + ey);
-    double dist = sqrt(rx * rx + ry * ry);
-    double nx = rx / dist, ny = ry / dist;
+    double rinv = 1.0 / sqrt(rx * rx + ry * ry);
+    double nx = rx * rinv, ny = ry * rinv;
     double Pj = P[j];
     double align = ((sxi - sx[j]) * nx + (syi - sy[j]) * ny) * w.ss;  // crate.py:347-349
     double fix = Pj + Pi - 2 * w.tp;                                   // crate.py:351
