@@ -91,9 +91,11 @@ int sc_abi_version(void);
 /* Lifetime.  capacity = most particles the context will ever hold (Crate: max_particles). */
 int sc_create(int device, int64_t capacity, sc_ctx** out);
 int sc_destroy(sc_ctx* ctx);
-/* Run on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) instead of the
- * context's own stream.  NULL restores the own stream. */
+/* Run on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) instead of the context's
+ * own stream; NULL is HIP's default stream, as everywhere in HIP.  sc_use_own_stream goes back to
+ * the private non-blocking stream the context was created with.  Both synchronise the old stream. */
 int sc_set_stream(sc_ctx* ctx, void* hip_stream);
+int sc_use_own_stream(sc_ctx* ctx);
 
 /* State in/out.  Replaces direct assignment of Crate.particles / particle_velocities
  * (crate.py:24-25).  Particle i gets id i; ids order ties exactly like the reference's
@@ -157,11 +159,33 @@ int sc_points_to_segments(int device, const double* xy, int64_t n, const double*
 /* Kernel timing with HIP events on the context's stream.  While enabled every kernel launch is
  * bracketed by two events; sc_get_timing synchronises and returns, per kernel, the summed
  * milliseconds and the number of launches since sc_reset_timing.  Names: sc_kernel_name(i). */
-#define SC_NUM_KERNELS 9
+#define SC_NUM_KERNELS 11
 int sc_enable_timing(sc_ctx* ctx, int on);
 int sc_reset_timing(sc_ctx* ctx);
 int sc_get_timing(sc_ctx* ctx, double* ms /*[SC_NUM_KERNELS]*/, int64_t* launches /*[SC_NUM_KERNELS]*/);
 const char* sc_kernel_name(int index);
+
+/* Multi-GPU x-slabs (no reference counterpart).  One context per GPU owns the
+ * grid columns [col_lo, col_hi), column = floor(x / diameter) of the position a particle has when
+ * the tick starts.  Particles within `halo` columns outside the slab are ghosts: they take part in
+ * the wall fix, the neighbor search and pass A exactly like owned particles, are never integrated,
+ * and are dropped at the end of the tick.  Ids are global (sc_upload_state_ids), so tie-breaks and
+ * the counter-based noise are the same as on one GPU.  Not available with SC_NOISE_HOST.
+ *
+ * Per tick:  sc_halo_pack -> exchange the two buffers with the neighbors (RCCL send/recv on
+ * the stream given to sc_set_stream, or any transport) -> sc_halo_unpack for each received buffer
+ * -> sc_step.  Buffers are DEVICE memory of (capacity_records + 1) * 5 doubles, caller-owned (e.g.
+ * torch tensors): record 0 is a header whose first field is the record count, records 1.. are
+ * (x, y, vx, vy, id).  sc_halo_pack writes every stored particle within `halo` columns of the
+ * left / right edge, including particles that have already moved out of the slab on that side
+ * (migrants: the receiver owns them from this tick on).  Nothing here synchronises. */
+int sc_set_slab(sc_ctx* ctx, int64_t col_lo, int64_t col_hi, int32_t halo, int32_t has_left, int32_t has_right);
+int sc_upload_state_ids(sc_ctx* ctx, const double* xy, const double* vxy, const int64_t* ids, int64_t n);
+int sc_halo_pack(sc_ctx* ctx, double* dev_left, double* dev_right, int64_t capacity_records);
+int sc_halo_unpack(sc_ctx* ctx, const double* dev_records, int64_t capacity_records);
+/* Synchronises.  Live particles stored in this context (dead ghost copies excluded); summed over
+ * the ranks this is the global particle count. */
+int sc_owned_count(sc_ctx* ctx, int64_t* n);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ LIB_PATH = Path(__file__).resolve().parent / "libsandcrate_hip.so"
 MAX_NEIGHBORS = 20
 MAX_SEGMENTS = 16
 MAX_BODIES = 8
-NUM_KERNELS = 9
+NUM_KERNELS = 11
 NOISE_NONE, NOISE_HOST, NOISE_COUNTER = 0, 1, 2
 ERR_DOMAIN = -5
 
@@ -54,6 +54,7 @@ SIGNATURES = {
     "sc_create": (C.c_int, [C.c_int, C.c_int64, C.POINTER(_P)]),
     "sc_destroy": (C.c_int, [_P]),
     "sc_set_stream": (C.c_int, [_P, _P]),
+    "sc_use_own_stream": (C.c_int, [_P]),
     "sc_upload_state": (C.c_int, [_P, _D, _D, C.c_int64]),
     "sc_append_particles": (C.c_int, [_P, _D, _D, C.c_int64]),
     "sc_count": (C.c_int, [_P, _I64]),
@@ -76,6 +77,11 @@ SIGNATURES = {
     "sc_reset_timing": (C.c_int, [_P]),
     "sc_get_timing": (C.c_int, [_P, _D, _I64]),
     "sc_kernel_name": (C.c_char_p, [C.c_int]),
+    "sc_set_slab": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "sc_upload_state_ids": (C.c_int, [_P, _D, _D, _I64, C.c_int64]),
+    "sc_halo_pack": (C.c_int, [_P, _P, _P, C.c_int64]),
+    "sc_halo_unpack": (C.c_int, [_P, _P, C.c_int64]),
+    "sc_owned_count": (C.c_int, [_P, _I64]),
 }
 
 _lib = None

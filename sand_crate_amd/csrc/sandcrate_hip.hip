@@ -39,9 +39,10 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(SC_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
-enum KernelId { K_APPEND = 0, K_WALL_BIN, K_SCAN, K_SCATTER, K_REORDER, K_NEIGHBORS, K_NOISE_OFFSETS, K_DENSITY, K_FORCE };
+enum KernelId { K_APPEND = 0, K_WALL_BIN, K_SCAN, K_SCATTER, K_REORDER, K_NEIGHBORS, K_NOISE_OFFSETS, K_DENSITY, K_FORCE, K_HALO_PACK, K_HALO_UNPACK };
 const char* kKernelNames[SC_NUM_KERNELS] = {"append",    "wall_bin",      "cell_scan", "scatter", "reorder",
-                                            "neighbors", "noise_offsets", "density",   "force_integrate"};
+                                            "neighbors", "noise_offsets", "density",   "force_integrate",
+                                            "halo_pack", "halo_unpack"};
 
 // Largest s with sqrt(s) <= R.  sqrt is correctly rounded and monotone, so for s >= 0
 // (sqrt(s) <= R) == (s <= threshold): the kernels compare squared distances and skip the sqrt
@@ -115,6 +116,11 @@ struct sc_ctx {
   long long grid_row0 = 0, grid_col0 = 0;
   int grid_nrows = 0, grid_ncols = 0;
   double custom_d = 0;
+  bool slab = false;
+  long long own_lo = 0, own_hi = 0;
+  int halo = 0, has_left = 0, has_right = 0;
+  int* stage_ids = nullptr;
+  int* owned_out = nullptr;
   World w{};
 
   bool timing = false;
@@ -153,6 +159,10 @@ struct Bracket {  // two HIP events around a launch when timing is on
 };
 
 int grid_for(int64_t n) { return (int)std::max<int64_t>(1, (n + kBlock - 1) / kBlock); }
+
+// In slab mode the stored count changes on the device every tick (halo records arrive without the
+// host knowing how many), so launches cover the capacity; surplus workgroups exit on their first load.
+int64_t launch_bound(const sc_ctx* c);
 
 int ensure_cells(sc_ctx* c, int64_t ncells) {
   if (ncells + 1 <= c->cellAlloc) return SC_OK;
@@ -253,8 +263,16 @@ int make_world(sc_ctx* c) {
     w.ccd_skip2 = (2 * w.d) * (2 * w.d) * (1 - 1e-6);
     long long cmin = (long long)std::floor(w.lo / w.d) - 3;
     long long cmax = (long long)std::floor(w.hi / w.d) + 3;
-    w.row0 = w.col0 = cmin - 1;
-    w.nrows = w.ncols = (int)(cmax - cmin + 1) + 2;
+    w.row0 = cmin - 1;
+    w.nrows = (int)(cmax - cmin + 1) + 2;
+    long long ccmin = cmin, ccmax = cmax;
+    if (c->slab) {  // local columns: the slab, its ghost band, one column of slack for the wall fix
+      ccmin = std::max(cmin, c->own_lo - c->halo - 1);
+      ccmax = std::min(cmax, c->own_hi + c->halo);
+      if (ccmax < ccmin) ccmax = ccmin;
+    }
+    w.col0 = ccmin - 1;
+    w.ncols = (int)(ccmax - ccmin + 1) + 2;
   }
   w.inv_d = 1.0 / w.d;
   w.nseg = c->nseg;
@@ -265,8 +283,12 @@ int make_world(sc_ctx* c) {
   w.noise_mode = c->noise_mode;
   w.tick = (int)c->tick;
   w.noise_key = host_mix64(c->seed + (uint64_t)(c->tick + 1) * 0x9E3779B97F4A7C15ull);
-  w.own_lo = std::numeric_limits<long long>::min();
-  w.own_hi = std::numeric_limits<long long>::max();
+  w.slab = c->slab ? 1 : 0;
+  w.own_lo = c->slab ? c->own_lo : std::numeric_limits<long long>::min();
+  w.own_hi = c->slab ? c->own_hi : std::numeric_limits<long long>::max();
+  w.halo = c->halo;
+  w.has_left = c->has_left;
+  w.has_right = c->has_right;
   return ensure_cells(c, (int64_t)w.nrows * w.ncols);
 }
 
@@ -280,10 +302,12 @@ int check_flags(int flags) {
   if (flags & F_NAN)
     return fail(SC_ERR_DOMAIN, "a particle position became NaN (zero distance to a wall, crate.py:206); it was dropped");
   if (flags & F_OUT_OF_GRID) return fail(SC_ERR_DOMAIN, "a particle left the cell grid; it was dropped");
+  if (flags & F_HALO_OVERFLOW) return fail(SC_ERR_CAPACITY, "a halo buffer was too small; ghost particles were lost");
+  if (flags & F_CAPACITY) return fail(SC_ERR_CAPACITY, "received halo particles exceed the context capacity");
   return SC_OK;
 }
 
-int put_particles(sc_ctx* c, const double* xy, const double* vxy, int64_t n, bool reset) {
+int put_particles(sc_ctx* c, const double* xy, const double* vxy, int64_t n, bool reset, const int64_t* ids = nullptr) {
   if (n < 0 || (n > 0 && (!xy || !vxy))) return fail(SC_ERR_ARG, "bad particle arrays");
   if (c->in_step) return fail(SC_ERR_STATE, "particles cannot change between sc_step_begin and sc_step_finish");
   int64_t base = reset ? 0 : c->upper;
@@ -299,9 +323,23 @@ int put_particles(sc_ctx* c, const double* xy, const double* vxy, int64_t n, boo
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(c->stage_xy, xy, 2 * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->stage_vxy, vxy, 2 * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int* dev_ids = nullptr;
+    int64_t max_id = -1;
+    std::vector<int> ids32;
+    if (ids) {
+      ids32.resize(n);
+      for (int64_t k = 0; k < n; ++k) {
+        if (ids[k] < 0 || ids[k] > std::numeric_limits<int>::max() - 1) return fail(SC_ERR_ARG, "particle id out of range");
+        ids32[k] = (int)ids[k];
+        max_id = std::max<int64_t>(max_id, ids[k]);
+      }
+      dev_ids = reinterpret_cast<int*>(c->stage_vxy + 2 * n);  // the staging buffer has 50 % headroom
+      HIPCHK(hipMemcpy(dev_ids, ids32.data(), n * sizeof(int), hipMemcpyHostToDevice));
+      c->next_id = std::max<int64_t>(c->next_id, max_id + 1 - n);
+    }
     Bracket br(c, K_APPEND);
     hipLaunchKernelGGL(k_append, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, c->stage_xy, c->stage_vxy, (int)n,
-                       (int)c->next_id, c->counters, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], reset ? 1 : 0);
+                       (int)c->next_id, dev_ids, c->counters, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], reset ? 1 : 0);
   }
   hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, c->stream, c->counters, (int)n, reset ? 1 : 0);
   HIPCHK(hipGetLastError());
@@ -309,6 +347,8 @@ int put_particles(sc_ctx* c, const double* xy, const double* vxy, int64_t n, boo
   c->next_id += n;
   return SC_OK;
 }
+
+int64_t launch_bound(const sc_ctx* c) { return c->slab ? c->cap : c->upper; }
 
 template <int NOISE>
 void launch_finish(sc_ctx* c, int grid, int cap) {
@@ -320,7 +360,7 @@ void launch_finish(sc_ctx* c, int grid, int cap) {
   {
     Bracket br(c, K_FORCE);
     hipLaunchKernelGGL(k_force<NOISE>, dim3(grid), dim3(kBlock), 0, c->stream, c->w, c->counters, c->x[1], c->y[1],
-                       c->vx[1], c->vy[1], c->id[1], c->wslotT, c->nbr, c->cnt, cap, c->eta, c->offById, c->P, c->sx,
+                       c->vx[1], c->vy[1], c->id[1], c->wslotT, c->cellT, c->nbr, c->cnt, cap, c->eta, c->offById, c->P, c->sx,
                        c->sy, c->wrec, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0]);
   }
 }
@@ -389,7 +429,7 @@ int sc_destroy(sc_ctx* c) {
   }
   void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->cellCount, c->cellStart, c->blockSums, c->wrec,
                   c->nbr, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
-                  c->stage_xy, c->stage_vxy};
+                  c->stage_xy, c->stage_vxy, c->owned_out};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& v : {c->ev_used, c->ev_free})
@@ -405,7 +445,14 @@ int sc_destroy(sc_ctx* c) {
 int sc_set_stream(sc_ctx* c, void* s) {
   if (!c) return fail(SC_ERR_ARG, "null context");
   HIPCHK(hipStreamSynchronize(c->stream));
-  c->stream = s ? (hipStream_t)s : c->own_stream;
+  c->stream = (hipStream_t)s;
+  return SC_OK;
+}
+
+int sc_use_own_stream(sc_ctx* c) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->stream = c->own_stream;
   return SC_OK;
 }
 
@@ -484,11 +531,12 @@ int sc_set_noise_mode(sc_ctx* c, int mode, uint64_t seed) {
 int sc_step_begin(sc_ctx* c) {
   if (!c) return fail(SC_ERR_ARG, "null context");
   if (c->in_step) return fail(SC_ERR_STATE, "sc_step_begin called twice");
+  if (c->slab && c->noise_mode == SC_NOISE_HOST) return fail(SC_ERR_STATE, "SC_NOISE_HOST is not available in slab mode");
   HIPCHK(hipSetDevice(c->device));
   int rc = make_world(c);
   if (rc) return rc;
   const World& w = c->w;
-  int grid = grid_for(c->upper);
+  int grid = grid_for(launch_bound(c));
   int cap = (int)c->cap;
   {
     Bracket br(c, K_WALL_BIN);
@@ -513,7 +561,7 @@ int sc_step_begin(sc_ctx* c) {
   }
   {
     Bracket br(c, K_NEIGHBORS);
-    int ngrid = (int)std::max<int64_t>(1, (c->upper + kNbrPerBlock - 1) / kNbrPerBlock);
+    int ngrid = (int)std::max<int64_t>(1, (launch_bound(c) + kNbrPerBlock - 1) / kNbrPerBlock);
     hipLaunchKernelGGL(k_neighbors, dim3(ngrid), dim3(kBlock), 0, c->stream, w, c->counters, c->x[1], c->y[1], c->cellT,
                        c->cellStart, c->nbr, c->cnt, cap);
   }
@@ -570,7 +618,7 @@ int sc_step_finish(sc_ctx* c) {
   if (!c->in_step) return fail(SC_ERR_STATE, "sc_step_finish needs sc_step_begin first");
   if (c->noise_mode == SC_NOISE_HOST && c->etaPairs < 0)
     return fail(SC_ERR_STATE, "SC_NOISE_HOST: sc_set_noise_host must be called every tick");
-  int grid = grid_for(c->upper);
+  int grid = grid_for(launch_bound(c));
   int cap = (int)c->cap;
   switch (c->noise_mode) {
     case SC_NOISE_HOST: launch_finish<SC_NOISE_HOST>(c, grid, cap); break;
@@ -587,6 +635,7 @@ int sc_step_finish(sc_ctx* c) {
 int sc_step(sc_ctx* c, int32_t n_ticks) {
   if (!c) return fail(SC_ERR_ARG, "null context");
   if (c->noise_mode == SC_NOISE_HOST) return fail(SC_ERR_STATE, "sc_step is not available in SC_NOISE_HOST mode");
+  if (c->slab && n_ticks > 1) return fail(SC_ERR_STATE, "slab mode: one tick per halo exchange");
   for (int t = 0; t < n_ticks; ++t) {
     int rc = sc_step_begin(c);
     if (rc) return rc;
@@ -626,9 +675,13 @@ int sc_download_state(sc_ctx* c, double* xy, double* vxy, double* pressure, int6
   int64_t np = c->normals_valid ? std::min<int64_t>(n, h[C_NT]) : 0;
   if (pressure && np > 0 && (rc = fetch(c, hp.data(), c->P, np * sizeof(double)))) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
-  std::vector<int> order(n);
-  std::iota(order.begin(), order.end(), 0);
+  std::vector<int> order;
+  order.reserve(n);
+  for (int64_t k = 0; k < n; ++k)
+    if (std::isfinite(hx[k])) order.push_back((int)k);  // slab mode leaves dead ghost copies (x = +inf) behind
   std::sort(order.begin(), order.end(), [&](int a, int b2) { return hid[a] < hid[b2]; });
+  n = (int64_t)order.size();
+  if (n_out) *n_out = n;
   for (int64_t k = 0; k < n; ++k) {
     int s = order[k];
     if (xy) {
@@ -811,6 +864,71 @@ int sc_points_to_segments(int device, const double* xy, int64_t n, const double*
   (void)hipFree(dnear);
   (void)hipFree(ddist);
   if (e != hipSuccess) return fail(SC_ERR_HIP, "sc_points_to_segments: %s", hipGetErrorString(e));
+  return SC_OK;
+}
+
+
+// ---- multi-GPU slabs ---------------------------------------------------------------------------
+
+int sc_set_slab(sc_ctx* c, int64_t col_lo, int64_t col_hi, int32_t halo, int32_t has_left, int32_t has_right) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  if (c->in_step) return fail(SC_ERR_STATE, "slab cannot change inside a tick");
+  if (col_hi <= col_lo || halo < 3) return fail(SC_ERR_ARG, "slab needs col_lo < col_hi and a halo of at least 3 columns");
+  c->slab = true;
+  c->own_lo = col_lo;
+  c->own_hi = col_hi;
+  c->halo = halo;
+  c->has_left = has_left ? 1 : 0;
+  c->has_right = has_right ? 1 : 0;
+  if (!c->owned_out) HIPCHK(dalloc(&c->owned_out, 1));
+  return SC_OK;
+}
+
+int sc_upload_state_ids(sc_ctx* c, const double* xy, const double* vxy, const int64_t* ids, int64_t n) {
+  if (!c || (n > 0 && !ids)) return fail(SC_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(c->device));
+  return put_particles(c, xy, vxy, n, true, ids);
+}
+
+int sc_halo_pack(sc_ctx* c, double* dev_left, double* dev_right, int64_t cap_records) {
+  if (!c || !dev_left || !dev_right || cap_records < 1) return fail(SC_ERR_ARG, "bad halo buffers");
+  if (!c->slab) return fail(SC_ERR_STATE, "sc_set_slab first");
+  if (c->in_step) return fail(SC_ERR_STATE, "halo exchange happens between ticks");
+  int rc = make_world(c);
+  if (rc) return rc;
+  Bracket br(c, K_HALO_PACK);
+  hipLaunchKernelGGL(k_halo_pack, dim3(grid_for(launch_bound(c))), dim3(kBlock), 0, c->stream, c->w, c->counters, c->x[0],
+                     c->y[0], c->vx[0], c->vy[0], c->id[0], dev_left, dev_right, (int)cap_records);
+  hipLaunchKernelGGL(k_halo_header, dim3(1), dim3(1), 0, c->stream, c->counters, dev_left, dev_right, (int)cap_records);
+  HIPCHK(hipGetLastError());
+  return SC_OK;
+}
+
+int sc_halo_unpack(sc_ctx* c, const double* dev_records, int64_t cap_records) {
+  if (!c || !dev_records || cap_records < 1) return fail(SC_ERR_ARG, "bad halo buffer");
+  if (!c->slab) return fail(SC_ERR_STATE, "sc_set_slab first");
+  if (c->in_step) return fail(SC_ERR_STATE, "halo exchange happens between ticks");
+  Bracket br(c, K_HALO_UNPACK);
+  hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(cap_records)), dim3(kBlock), 0, c->stream, dev_records, (int)cap_records,
+                     c->counters, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], (int)c->cap);
+  hipLaunchKernelGGL(k_halo_bump, dim3(1), dim3(1), 0, c->stream, dev_records, (int)cap_records, c->counters, (int)c->cap);
+  HIPCHK(hipGetLastError());
+  return SC_OK;
+}
+
+int sc_owned_count(sc_ctx* c, int64_t* n) {
+  if (!c || !n) return fail(SC_ERR_ARG, "null argument");
+  if (c->in_step) return fail(SC_ERR_STATE, "sc_owned_count inside a tick");
+  int rc = c->slab ? make_world(c) : SC_OK;
+  if (rc) return rc;
+  if (!c->owned_out) HIPCHK(dalloc(&c->owned_out, 1));
+  HIPCHK(hipMemsetAsync(c->owned_out, 0, sizeof(int), c->stream));
+  hipLaunchKernelGGL(k_owned_count, dim3(grid_for(launch_bound(c))), dim3(kBlock), 0, c->stream, c->w, c->counters, c->x[0],
+                     c->owned_out);
+  int h = 0;
+  HIPCHK(hipMemcpyAsync(&h, c->owned_out, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *n = h;
   return SC_OK;
 }
 

@@ -45,8 +45,11 @@ struct World {
   int noise_mode;
   int tick;
   unsigned long long noise_key;
-  // slab decomposition (single GPU: owns every column)
-  long long own_lo, own_hi;
+  // slab decomposition (single GPU: slab = 0 and every column is owned).  Columns are
+  // floor(x / d) of the position a particle has when the tick starts.
+  long long own_lo, own_hi;  // owned columns [own_lo, own_hi)
+  int slab, halo;            // slab mode on/off; ghost band width in columns
+  int has_left, has_right;
   Seg seg[kMaxSeg];
   Seg pad[2 * kMaxSeg];
   BodyK body[kMaxBody];
@@ -61,10 +64,16 @@ enum Counter {
   C_SUMC = 4,   // sum of neighbor counts (low 32 bits)
   C_MAXC = 5,   // max neighbor count
   C_SUMC_HI = 6,
-  C_COUNT = 8
+  C_PACK_L = 7,  // halo records packed for the left / right neighbor this tick
+  C_PACK_R = 8,
+  C_COUNT = 10
 };
 
-enum Flag { F_OUT_OF_GRID = 1, F_NAN = 2 };
+enum Flag { F_OUT_OF_GRID = 1, F_NAN = 2, F_HALO_OVERFLOW = 4, F_CAPACITY = 8 };
+
+constexpr int kGhostBit = 1 << 30;  // set in a particle's packed cell index when it is a ghost
+constexpr int kCellMask = kGhostBit - 1;
+constexpr int kHaloFields = 5;      // x, y, vx, vy, id per halo record
 
 // Counter-based collider noise: two uniforms in [0,1) with 32 bits each from one 64-bit hash of
 // (tick key, particle id, slot).  oracle/tick.py:counter_noise_u01 is the same function.

@@ -26,7 +26,7 @@ __device__ __forceinline__ double closest_on_segment(const Seg& s, double px, do
 // K0  append: crate.py:138-147 (create_new_particles).  Host arrays are P x 2 interleaved.
 // ------------------------------------------------------------------------------------------
 __global__ void k_append(const double* __restrict__ xy, const double* __restrict__ vxy, int m, int first_id,
-                         int* __restrict__ counters, double* __restrict__ x, double* __restrict__ y,
+                         const int* __restrict__ ids, int* __restrict__ counters, double* __restrict__ x, double* __restrict__ y,
                          double* __restrict__ vx, double* __restrict__ vy, int* __restrict__ id, int reset) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   int base = reset ? 0 : counters[C_NS];
@@ -35,7 +35,7 @@ __global__ void k_append(const double* __restrict__ xy, const double* __restrict
     y[base + k] = xy[2 * k + 1];
     vx[base + k] = vxy[2 * k];
     vy[base + k] = vxy[2 * k + 1];
-    id[base + k] = first_id + k;
+    id[base + k] = ids ? ids[k] : first_id + k;
   }
   // every block reads `base` before any block may bump the counter: the bump happens in a
   // separate one-thread launch (k_bump) ordered after this kernel on the stream.
@@ -60,7 +60,12 @@ __device__ __forceinline__ int wall_and_cell(const World& w, int i, int* __restr
                                              double* __restrict__ wrec) {
   if (i >= counters[C_NS]) return -1;
   double px = x[i], py = y[i];
-  if (px < w.lo || px > w.hi || py < w.lo || py > w.hi) return -1;  // crate.py:152
+  if (px < w.lo || px > w.hi || py < w.lo || py > w.hi) return -1;  // crate.py:152 (dead ghosts carry x = +inf)
+  bool ghost = false;
+  if (w.slab) {
+    long long col = (long long)floor(px / w.d);
+    ghost = col < w.own_lo || col >= w.own_hi;
+  }
   // bounding-box reject (exact-safe: the boxes are inflated far beyond rounding error)
   unsigned cand = 0;
   bool far = true;
@@ -139,11 +144,11 @@ __device__ __forceinline__ int wall_and_cell(const World& w, int i, int* __restr
   double fr = floor(py / w.d), fc = floor(px / w.d);  // collision_detector.py:126
   long long lr = (long long)fr - w.row0, lc = (long long)fc - w.col0;
   if (!(fabs(fr) < 9e15) || !(fabs(fc) < 9e15) || lr < 1 || lr > w.nrows - 2 || lc < 1 || lc > w.ncols - 2) {
-    atomicOr(&counters[C_FLAGS], F_OUT_OF_GRID);
+    if (!ghost) atomicOr(&counters[C_FLAGS], F_OUT_OF_GRID);  // a ghost beyond the local grid is simply not needed
     return -1;
   }
   wslotS[i] = wslot;
-  return (int)lr * w.ncols + (int)lc;
+  return ((int)lr * w.ncols + (int)lc) | (ghost ? kGhostBit : 0);
 }
 
 
@@ -155,8 +160,8 @@ __global__ void __launch_bounds__(kBlock) k_wall_bin(World w, int* __restrict__ 
   int c = wall_and_cell(w, i, counters, x, y, wslotS, wrec);
   if (i < counters[C_NS]) cellS[i] = c;
   // one atomic per run of equal cells in the wave; lanes without a cell get distinct negative keys
-  LaneRun run = lane_run(c >= 0 ? c : -1 - (int)(threadIdx.x & 63));
-  if (run.is_head && c >= 0) atomicAdd(&cellCount[c], run.len);
+  LaneRun run = lane_run(c >= 0 ? (c & kCellMask) : -1 - (int)(threadIdx.x & 63));
+  if (run.is_head && c >= 0) atomicAdd(&cellCount[c & kCellMask], run.len);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -231,6 +236,7 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ coun
                                                     int* __restrict__ keyId) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int c = i < counters[C_NS] ? cellS[i] : -1;
+  if (c >= 0) c &= kCellMask;
   const int lane = threadIdx.x & 63;
   LaneRun run = lane_run(c >= 0 ? c : -1 - lane);
   int base = 0;
@@ -262,7 +268,8 @@ __global__ void __launch_bounds__(kBlock)
   int i = perm[s];
   double xi = keyX[s];
   int idi = keyId[s];
-  int c = cellS[i];
+  int cpacked = cellS[i];
+  int c = cpacked & kCellMask;
   double yi = yS[i], vxi = vxS[i], vyi = vyS[i];
   int wsi = wslotS[i];
   int b = cellStart[c], e = cellStart[c + 1];
@@ -283,7 +290,7 @@ __global__ void __launch_bounds__(kBlock)
   vxT[dst] = vxi;
   vyT[dst] = vyi;
   idT[dst] = idi;
-  cellT[dst] = c;
+  cellT[dst] = cpacked;
   wslotT[dst] = wsi;
 }
 
@@ -319,7 +326,7 @@ __global__ void __launch_bounds__(kBlock)
     const int i = i0 + local;
     int base = 0;
     if (i < n) {  // uniform inside the group
-      const int c = cell[i];
+      const int c = cell[i] & kCellMask;
       const double xi = x[i], yi = y[i];
       const double xhi = xi + w.d, xlo = xi - w.d;
       const int e0 = cellStart[c + 2], b0 = cellStart[c - 1];
@@ -487,7 +494,8 @@ template <int NOISE>
 __global__ void __launch_bounds__(kBlock)
     k_force(World w, int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
             const double* __restrict__ vx, const double* __restrict__ vy, const int* __restrict__ id,
-            const int* __restrict__ wslot, const int* __restrict__ nbr, const unsigned char* __restrict__ cnt, int cap,
+            const int* __restrict__ wslot, const int* __restrict__ cell, const int* __restrict__ nbr,
+            const unsigned char* __restrict__ cnt, int cap,
             const double* __restrict__ eta, const int* __restrict__ offById, const double* __restrict__ P,
             const double* __restrict__ sx, const double* __restrict__ sy, const double* __restrict__ wrec,
             double* __restrict__ xo, double* __restrict__ yo, double* __restrict__ vxo, double* __restrict__ vyo,
@@ -502,6 +510,15 @@ __global__ void __launch_bounds__(kBlock)
     counters[C_MAXC] = 0;
   }
   if (i >= n) return;
+  if (w.slab && (cell[i] & kGhostBit)) {
+    // ghosts served as neighbors only; +inf makes next tick's removal test (crate.py:152) drop the copy
+    xo[i] = __builtin_huge_val();
+    yo[i] = 0.0;
+    vxo[i] = 0.0;
+    vyo[i] = 0.0;
+    ido[i] = -1;
+    return;
+  }
   int C = cnt[i];
   double xi = x[i], yi = y[i];
   double vxi = vx[i], vyi = vy[i];
@@ -597,6 +614,93 @@ __global__ void __launch_bounds__(kBlock)
   vxo[i] = vxi;
   vyo[i] = vyi;
   ido[i] = idi;
+}
+
+// ------------------------------------------------------------------------------------------
+// Halo exchange for x-slabs (no reference counterpart).  Records are
+// (x, y, vx, vy, id) as five doubles; record 0 of a buffer is a header whose first field is the
+// record count, so one fixed-size message per direction carries everything and the host never
+// needs to know the count.
+//   k_halo_pack   every stored particle within `halo` columns of a slab edge -- including those
+//                 that already left the slab on that side (migrants) -- goes to that neighbor.
+//   k_halo_header publishes the counts and re-arms the counters.
+//   k_halo_unpack appends a received buffer to the storage arrays; whether a record is owned or
+//                 a ghost here is decided by its column in K1, not by the sender.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+    k_halo_pack(World w, int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
+                const double* __restrict__ vx, const double* __restrict__ vy, const int* __restrict__ id,
+                double* __restrict__ left, double* __restrict__ right, int cap) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= counters[C_NS]) return;
+  double px = x[i];
+  if (!(fabs(px) < 1e300)) return;  // dead ghost copy (x = +inf)
+  long long col = (long long)floor(px / w.d);
+  bool toL = w.has_left && col < w.own_lo + w.halo;
+  bool toR = w.has_right && col >= w.own_hi - w.halo;
+  if (!toL && !toR) return;
+  double py = y[i], pvx = vx[i], pvy = vy[i], pid = (double)id[i];
+  if (toL) {
+    int k = atomicAdd(&counters[C_PACK_L], 1);
+    if (k < cap) {
+      double* r = left + (size_t)kHaloFields * (k + 1);
+      r[0] = px; r[1] = py; r[2] = pvx; r[3] = pvy; r[4] = pid;
+    }
+  }
+  if (toR) {
+    int k = atomicAdd(&counters[C_PACK_R], 1);
+    if (k < cap) {
+      double* r = right + (size_t)kHaloFields * (k + 1);
+      r[0] = px; r[1] = py; r[2] = pvx; r[3] = pvy; r[4] = pid;
+    }
+  }
+}
+
+__global__ void k_halo_header(int* __restrict__ counters, double* __restrict__ left, double* __restrict__ right, int cap) {
+  int nl = counters[C_PACK_L], nr = counters[C_PACK_R];
+  if (nl > cap || nr > cap) atomicOr(&counters[C_FLAGS], F_HALO_OVERFLOW);
+  left[0] = (double)min(nl, cap);
+  right[0] = (double)min(nr, cap);
+  counters[C_PACK_L] = 0;
+  counters[C_PACK_R] = 0;
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_halo_unpack(const double* __restrict__ buf, int cap, int* __restrict__ counters, double* __restrict__ x,
+                  double* __restrict__ y, double* __restrict__ vx, double* __restrict__ vy, int* __restrict__ id,
+                  int capS) {
+  int n = min((int)buf[0], cap);
+  int base = counters[C_NS];
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  if (base + k >= capS) {
+    atomicOr(&counters[C_FLAGS], F_CAPACITY);
+    return;
+  }
+  const double* r = buf + (size_t)kHaloFields * (k + 1);
+  x[base + k] = r[0];
+  y[base + k] = r[1];
+  vx[base + k] = r[2];
+  vy[base + k] = r[3];
+  id[base + k] = (int)r[4];
+}
+
+__global__ void k_halo_bump(const double* __restrict__ buf, int cap, int* __restrict__ counters, int capS) {
+  int n = min((int)buf[0], cap);
+  counters[C_NS] = min(counters[C_NS] + n, capS);
+}
+
+// live particles in the storage arrays: everything but the dead ghost copies (x = +inf) a slab tick
+// leaves behind.  Across ranks every particle is stored live exactly once.
+__global__ void __launch_bounds__(kBlock) k_owned_count(World w, const int* __restrict__ counters,
+                                                        const double* __restrict__ x, int* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int own = 0;
+  if (i < counters[C_NS]) {
+    own = fabs(x[i]) < 1e300;
+  }
+  int s = wave_sum(own);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
 }
 
 // geometry_utils.py:7-39 as a stand-alone kernel (the reference's tests pin it): one thread per

@@ -43,8 +43,12 @@ class Engine:
         except Exception:
             pass
 
-    def set_stream(self, stream_handle: int | None) -> None:
-        N.check(self._lib.sc_set_stream(self._ctx, N._P(stream_handle) if stream_handle else None))
+    def set_stream(self, stream_handle: int) -> None:
+        """Enqueue on this hipStream_t (0 = HIP's default stream), e.g. torch's current stream."""
+        N.check(self._lib.sc_set_stream(self._ctx, N._P(int(stream_handle))))
+
+    def use_own_stream(self) -> None:
+        N.check(self._lib.sc_use_own_stream(self._ctx))
 
     # -- state
     def upload(self, particles, velocities) -> None:
@@ -52,6 +56,14 @@ class Engine:
         if p.shape != v.shape:
             raise ValueError("particles and velocities must both be P x 2")
         N.check(self._lib.sc_upload_state(self._ctx, N.dptr(p), N.dptr(v), len(p)))
+
+    def upload_with_ids(self, particles, velocities, ids) -> None:
+        """Slab mode: the particles this GPU owns, carrying their global ids."""
+        p, v = N.f64(particles).reshape(-1, 2), N.f64(velocities).reshape(-1, 2)
+        i = np.ascontiguousarray(ids, dtype=np.int64).reshape(-1)
+        if not (len(p) == len(v) == len(i)):
+            raise ValueError("particles, velocities and ids must have one row per particle")
+        N.check(self._lib.sc_upload_state_ids(self._ctx, N.dptr(p), N.dptr(v), N.i64ptr(i), len(p)))
 
     def append(self, particles, velocities) -> None:
         p, v = N.f64(particles).reshape(-1, 2), N.f64(velocities).reshape(-1, 2)
@@ -150,6 +162,21 @@ class Engine:
         n = C.c_int64(0)
         N.check(self._lib.sc_download_normals(self._ctx, N.dptr(s), room, C.byref(n)))
         return s[:n.value].copy()
+
+    # -- multi-GPU slabs (device pointers are plain integers, e.g. torch_tensor.data_ptr())
+    def set_slab(self, col_lo: int, col_hi: int, halo: int, has_left: bool, has_right: bool) -> None:
+        N.check(self._lib.sc_set_slab(self._ctx, int(col_lo), int(col_hi), int(halo), int(has_left), int(has_right)))
+
+    def halo_pack(self, dev_left: int, dev_right: int, capacity_records: int) -> None:
+        N.check(self._lib.sc_halo_pack(self._ctx, N._P(dev_left), N._P(dev_right), int(capacity_records)))
+
+    def halo_unpack(self, dev_records: int, capacity_records: int) -> None:
+        N.check(self._lib.sc_halo_unpack(self._ctx, N._P(dev_records), int(capacity_records)))
+
+    def owned_count(self) -> int:
+        n = C.c_int64(0)
+        N.check(self._lib.sc_owned_count(self._ctx, C.byref(n)))
+        return n.value
 
     # -- timing
     def enable_timing(self, on: bool = True) -> None:

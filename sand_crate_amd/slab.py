@@ -1,0 +1,268 @@
+"""Multi-GPU: the particle update sharded into x-slabs, one process per GPU, ghost particles
+exchanged with the two neighbor ranks every tick (the reference has no
+multi-device code, so this is new design, checked against the single-domain result).
+
+Decomposition
+    column = floor(x / diameter) of a particle's position at the start of the tick.  Rank k owns the
+    columns [lo_k, hi_k); cuts are chosen once from the initial column histogram so that every rank
+    starts with about the same number of particles.
+Ghost band
+    3 columns on each side.  Interaction range is one diameter after the hard wall fix, which moves
+    a particle by at most 0.1 d per wall contact, and pass B needs pressure and surface normal of
+    the neighbors of owned particles, which need THEIR neighbors: 2 x 1.2 d = 2.4 d < 3 columns.
+Per tick
+    pack (device) -> one fixed-size message to each neighbor (RCCL send/recv over xGMI when the
+    process group is NCCL; staged through the host for gloo) -> unpack (device) -> the ordinary tick.
+    A record is (x, y, vx, vy, id); record 0 of a message is the count, so the host never needs to
+    know how many particles cross.  A particle that has left its slab is in the message too and is
+    owned by the receiver from then on (migration rides the halo message).  There is no other
+    collective on the data path.
+Same results as one GPU
+    ids are global, tie-breaks use ids, and the collider noise is the counter-based hash of
+    (seed, tick, id, slot), so an owned particle sees the same neighbor list, in the same order,
+    with the same noise as in the single-domain run.
+"""
+from __future__ import annotations
+
+import copy
+import math
+
+import numpy as np
+
+from .crate import _NOISE_MODES, _TICK_COEFFICIENTS
+from .rigid_body import build_rigid_bodies
+from .utils.geometry_utils import pad_segments
+
+HALO_COLUMNS = 3
+HALO_FIELDS = 5
+
+
+def column_of(x: np.ndarray, diameter: float) -> np.ndarray:
+    return np.floor(np.asarray(x, dtype=np.float64) / diameter).astype(np.int64)
+
+
+def partition_columns(columns: np.ndarray, n_slabs: int, halo: int = HALO_COLUMNS) -> list[tuple[int, int]]:
+    """Cuts [lo_k, hi_k) at column granularity with about equal particle counts; the outer slabs
+    are open-ended.  Every slab is at least 2*halo + 2 columns wide so that a particle can be a
+    ghost of at most one neighbor on each side."""
+    big = 2 ** 40
+    if n_slabs == 1:
+        return [(-big, big)]
+    cmin, cmax = int(columns.min()), int(columns.max())
+    min_width = 2 * halo + 2
+    if (cmax - cmin + 1) < n_slabs * min_width:
+        raise ValueError(f"{cmax - cmin + 1} columns cannot be split into {n_slabs} slabs of >= {min_width} columns")
+    hist = np.bincount(columns - cmin, minlength=cmax - cmin + 1)
+    cum = np.cumsum(hist)
+    cuts = []
+    prev = cmin
+    for k in range(1, n_slabs):
+        target = cum[-1] * k / n_slabs
+        c = cmin + int(np.searchsorted(cum, target, side="left")) + 1
+        c = max(c, prev + min_width)
+        c = min(c, cmax + 1 - (n_slabs - k) * min_width)
+        cuts.append(c)
+        prev = c
+    bounds = [-big] + cuts + [big]
+    return [(bounds[k], bounds[k + 1]) for k in range(n_slabs)]
+
+
+class HipSlabBackend:
+    """The compute side of one slab on one GPU: an `Engine` in slab mode plus halo buffers held as
+    torch tensors (device memory and stream plumbing only)."""
+
+    def __init__(self, capacity: int, halo_capacity: int, device: int, noise: str, noise_seed: int):
+        import torch
+
+        from . import _native as N
+        from .engine import Engine
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.engine = Engine(capacity, device=device)
+        self.engine.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.engine.set_noise_mode(_NOISE_MODES[noise], noise_seed)
+        self.halo_capacity = int(halo_capacity)
+        shape = ((self.halo_capacity + 1) * HALO_FIELDS,)
+        self.send_left = torch.zeros(shape, dtype=torch.float64, device=self.device)
+        self.send_right = torch.zeros(shape, dtype=torch.float64, device=self.device)
+        self.recv_left = torch.zeros(shape, dtype=torch.float64, device=self.device)
+        self.recv_right = torch.zeros(shape, dtype=torch.float64, device=self.device)
+        self._N = N
+
+    def load(self, particles, velocities, ids) -> None:
+        self.engine.upload_with_ids(particles, velocities, ids)
+
+    def set_slab(self, lo, hi, halo, has_left, has_right) -> None:
+        self.engine.set_slab(lo, hi, halo, has_left, has_right)
+
+    def set_tick_inputs(self, coef, gravity, segments, padded, bodies) -> None:
+        self.engine.set_params(gravity=gravity, **coef)
+        self.engine.set_segments(segments, padded, bodies)
+
+    def pack(self) -> None:
+        self.engine.halo_pack(self.send_left.data_ptr(), self.send_right.data_ptr(), self.halo_capacity)
+
+    def unpack(self, side: str) -> None:
+        buf = self.recv_left if side == "left" else self.recv_right
+        self.engine.halo_unpack(buf.data_ptr(), self.halo_capacity)
+
+    def step(self) -> None:
+        self.engine.step(1)
+
+    def synchronize(self) -> None:
+        self.engine.synchronize()
+
+    def owned_count(self) -> int:
+        return self.engine.owned_count()
+
+    def download_owned(self):
+        return self.engine.download()
+
+
+class SlabCrate:
+    """`Crate.run()`-style stepping of one slab per rank.  Every rank constructs it with the FULL
+    initial state (so all ranks derive the same cuts) and keeps its own slab."""
+
+    def __init__(self, world_config, particles, velocities, *, device: int = 0, noise: str = "counter",
+                 noise_seed: int = 0, group=None, backend=None, halo_capacity: int | None = None,
+                 capacity: int | None = None):
+        import torch.distributed as dist
+        if noise == "host":
+            raise ValueError("slabs need noise='counter' or 'none' (the host MT19937 stream is one global sequence)")
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.world_config = world_config
+        self.rigid_bodies = build_rigid_bodies(world_config.rigid_bodies)
+        if world_config.particle_sources:
+            raise ValueError("SlabCrate runs the update only; particle sources stay with the single-GPU Crate")
+        for name, value in world_config.coefficients.items():
+            setattr(self, name, value)
+        self.gravity = np.array(world_config.coefficients["gravity"], dtype=np.float64)
+        self.tick = 0
+
+        p = np.ascontiguousarray(particles, dtype=np.float64).reshape(-1, 2)
+        v = np.ascontiguousarray(velocities, dtype=np.float64).reshape(-1, 2)
+        d = self.particle_radius * 2
+        cols = column_of(p[:, 0], d)
+        self.slabs = partition_columns(cols, self.world)
+        self.lo, self.hi = self.slabs[self.rank]
+        own = (cols >= self.lo) & (cols < self.hi)
+        ids = np.flatnonzero(own).astype(np.int64)
+        n_own = int(own.sum())
+        rows = max(1.0, 1.0 / d)
+        expect_halo = HALO_COLUMNS * rows * (len(p) / max(rows * rows, 1.0))
+        if halo_capacity is None:
+            halo_capacity = int(2.5 * expect_halo) + 4096
+        if capacity is None:
+            capacity = int(1.3 * len(p) / self.world) + 4 * halo_capacity + 1024
+            capacity = max(capacity, n_own + 4 * halo_capacity + 1024)
+        self.left = self.rank - 1 if self.rank > 0 else None
+        self.right = self.rank + 1 if self.rank < self.world - 1 else None
+        self.backend = backend if backend is not None else HipSlabBackend(capacity, halo_capacity, device, noise, noise_seed)
+        self.backend.set_slab(self.lo, self.hi, HALO_COLUMNS, self.left is not None, self.right is not None)
+        self.backend.load(p[own], v[own], ids)
+        self._host_staged = dist.is_initialized() and dist.get_backend(group) != "nccl"
+        self._stage = {}
+
+    # ------------------------------------------------------------------ stepping
+    @property
+    def engine(self):
+        return self.backend.engine
+
+    def _tick_inputs(self):
+        coef = {name: getattr(self, name) for name in _TICK_COEFFICIENTS}
+        seg = np.vstack([b.segments for b in self.rigid_bodies]) if self.rigid_bodies else np.zeros((0, 2, 2))
+        pad = pad_segments(seg, self.particle_radius) if len(seg) else np.zeros((0, 2, 2))
+        bodies = [(b.position, b.center_velocity, b.angular_clockwise_velocity, len(b)) for b in self.rigid_bodies]
+        return coef, seg, pad, bodies
+
+    def _exchange(self) -> None:
+        """One message each way with each existing neighbor."""
+        if self.world == 1:
+            return
+        dist, be = self.dist, self.backend
+        pairs = []  # (peer, send tensor, recv tensor)
+        if self.left is not None:
+            pairs.append((self.left, be.send_left, be.recv_left))
+        if self.right is not None:
+            pairs.append((self.right, be.send_right, be.recv_right))
+        if self._host_staged:
+            staged = []
+            for peer, send, recv in pairs:
+                key = (peer, "r")
+                if key not in self._stage:
+                    self._stage[key] = send.new_empty(send.shape, device="cpu")
+                staged.append((peer, send.to("cpu"), self._stage[key], recv))
+            ops = []
+            for peer, s_cpu, r_cpu, _ in staged:
+                ops.append(dist.P2POp(dist.isend, s_cpu, peer, self.group))
+                ops.append(dist.P2POp(dist.irecv, r_cpu, peer, self.group))
+            for work in dist.batch_isend_irecv(ops):
+                work.wait()
+            for _, _, r_cpu, recv in staged:
+                recv.copy_(r_cpu)
+        else:
+            ops = []
+            for peer, send, recv in pairs:
+                ops.append(dist.P2POp(dist.isend, send, peer, self.group))
+                ops.append(dist.P2POp(dist.irecv, recv, peer, self.group))
+            for work in dist.batch_isend_irecv(ops):
+                work.wait()  # stream-ordered for NCCL: the current stream waits, the host does not
+
+    def run(self, n_ticks: int) -> None:
+        be = self.backend
+        for _ in range(n_ticks):
+            for body in self.rigid_bodies:
+                body.apply_velocity(self.dt)
+            coef, seg, pad, bodies = self._tick_inputs()
+            be.set_tick_inputs(coef, self.gravity, seg, pad, bodies)
+            if self.world > 1:
+                be.pack()
+                self._exchange()
+                if self.left is not None:
+                    be.unpack("left")
+                if self.right is not None:
+                    be.unpack("right")
+            be.step()
+            self.tick += 1
+
+    def physics_tick(self) -> None:
+        self.run(1)
+
+    def synchronize(self) -> None:
+        self.backend.synchronize()
+
+    # ------------------------------------------------------------------ results
+    def owned_state(self):
+        """-> particles, velocities, pressure, ids of the particles this rank owns (id order)."""
+        # Particles that moved out of the slab during the last tick still sit here until the next
+        # exchange, so every particle is reported by exactly one rank: the one that integrated it.
+        return self.backend.download_owned()
+
+    def global_particle_count(self) -> int:
+        n = self.backend.owned_count()
+        if self.world == 1:
+            return n
+        import torch
+        dev = "cpu" if self._host_staged else self.backend.device
+        t = torch.tensor([n], dtype=torch.int64, device=dev)
+        self.dist.all_reduce(t, group=self.group)
+        return int(t.item())
+
+    def gather_state(self):
+        """All ranks -> (particles, velocities, pressure, ids) of the whole domain in id order (a
+        verification helper: it moves everything through the host)."""
+        mine = self.owned_state()
+        if self.world == 1:
+            return mine
+        parts = [None] * self.world
+        self.dist.all_gather_object(parts, mine, group=self.group)
+        p = np.concatenate([x[0] for x in parts])
+        v = np.concatenate([x[1] for x in parts])
+        pr = np.concatenate([x[2] for x in parts])
+        ids = np.concatenate([x[3] for x in parts])
+        order = np.argsort(ids, kind="stable")
+        return p[order], v[order], pr[order], ids[order]

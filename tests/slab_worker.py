@@ -1,0 +1,60 @@
+"""Worker launched by torch.distributed.run: runs a SlabCrate for a few ticks and has rank 0 save the
+gathered state.  --backend oracle needs no GPU (gloo); --backend hip puts every rank on cuda:0."""
+import argparse
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def synthetic_world(n, noise_level, vel, margin=0.0, seed=5):
+    import sand_crate_amd as sc
+    rs = np.random.RandomState(seed)
+    d = float(np.sqrt(12 / (np.pi * n)))
+    p = rs.rand(n, 2) * (1 - 2 * margin) + margin
+    v = (rs.rand(n, 2) - 0.5) * vel
+    cfg = sc.load_config(ROOT / "config" / "wave_machine.yaml")
+    co = cfg.world_config.coefficients
+    co.update(particle_radius=d / 2, dt=0.002 * d / 0.01, collider_noise_level=noise_level, max_particles=n)
+    cfg.world_config.particle_sources = []
+    return cfg.world_config, p, v
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", default="oracle")
+    ap.add_argument("--particles", type=int, default=3000)
+    ap.add_argument("--ticks", type=int, default=4)
+    ap.add_argument("--vel", type=float, default=30.0)
+    ap.add_argument("--noise", default="counter")
+    ap.add_argument("--margin", type=float, default=0.0)
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    import torch.distributed as dist
+
+    from sand_crate_amd.slab import SlabCrate
+    dist.init_process_group("gloo")
+    wc, p, v = synthetic_world(a.particles, 0.1 if a.noise == "counter" else 0.0, a.vel, margin=a.margin)
+    backend = None
+    if a.backend == "oracle":
+        from slab_oracle_backend import OracleSlabBackend
+        backend = OracleSlabBackend(halo_capacity=a.particles, noise=a.noise, noise_seed=9)
+    sim = SlabCrate(wc, p, v, device=0, noise=a.noise, noise_seed=9, backend=backend)
+    sim.run(a.ticks)
+    sim.synchronize()
+    count = sim.global_particle_count()
+    gp, gv, gpr, gids = sim.gather_state()
+    if dist.get_rank() == 0:
+        np.savez(a.out, particles=gp, velocities=gv, pressure=gpr, ids=gids, count=count,
+                 slabs=np.array(sim.slabs, dtype=np.float64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
