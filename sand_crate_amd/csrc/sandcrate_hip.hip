@@ -16,6 +16,7 @@
 
 #include "sandcrate_hip.h"
 #include "sc_kernels.h"
+#include "sc_tiled.h"
 
 using namespace sc;
 
@@ -39,10 +40,10 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(SC_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
-enum KernelId { K_APPEND = 0, K_WALL_BIN, K_SCAN, K_SCATTER, K_REORDER, K_NEIGHBORS, K_NOISE_OFFSETS, K_DENSITY, K_FORCE, K_HALO_PACK, K_HALO_UNPACK };
+enum KernelId { K_APPEND = 0, K_WALL_BIN, K_SCAN, K_SCATTER, K_REORDER, K_NEIGHBORS, K_NOISE_OFFSETS, K_DENSITY, K_FORCE, K_HALO_PACK, K_HALO_UNPACK, K_PASS_A };
 const char* kKernelNames[SC_NUM_KERNELS] = {"append",    "wall_bin",      "cell_scan", "scatter", "reorder",
                                             "neighbors", "noise_offsets", "density",   "force_integrate",
-                                            "halo_pack", "halo_unpack"};
+                                            "halo_pack", "halo_unpack", "neighbors_density"};
 
 // Largest s with sqrt(s) <= R.  sqrt is correctly rounded and monotone, so for s >= 0
 // (sqrt(s) <= R) == (s <= threshold): the kernels compare squared distances and skip the sqrt
@@ -83,6 +84,7 @@ struct sc_ctx {
   int *cellS = nullptr, *wslotS = nullptr, *cellT = nullptr, *wslotT = nullptr, *perm = nullptr;
   double* keyX = nullptr;
   int* keyId = nullptr;
+  int* tileBounds = nullptr;
   int *cellCount = nullptr, *cellStart = nullptr, *blockSums = nullptr;
   int64_t cellAlloc = 0;
   double* wrec = nullptr;
@@ -350,19 +352,23 @@ int put_particles(sc_ctx* c, const double* xy, const double* vxy, int64_t n, boo
 
 int64_t launch_bound(const sc_ctx* c) { return c->slab ? c->cap : c->upper; }
 
+int tile_grid(const sc_ctx* c) { return (int)std::max<int64_t>(1, (launch_bound(c) + kTileW - 1) / kTileW); }
+
+// neighbor search (+ pass A unless the host's noise block has to be indexed first)
+template <int NOISE, bool ENUM, bool DENS>
+void launch_pass_a(sc_ctx* c, int kernel_id) {
+  Bracket br(c, kernel_id);
+  hipLaunchKernelGGL((k_pass_a<NOISE, ENUM, DENS>), dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters,
+                     c->x[1], c->y[1], c->id[1], c->cellT, c->cellStart, c->nbr, c->cnt, (int)c->cap, c->eta, c->offById,
+                     c->P, c->sx, c->sy, c->tileBounds);
+}
+
 template <int NOISE>
-void launch_finish(sc_ctx* c, int grid, int cap) {
-  {
-    Bracket br(c, K_DENSITY);
-    hipLaunchKernelGGL(k_density<NOISE>, dim3(grid), dim3(kBlock), 0, c->stream, c->w, c->counters, c->x[1], c->y[1],
-                       c->id[1], c->nbr, c->cnt, cap, c->eta, c->offById, c->P, c->sx, c->sy);
-  }
-  {
-    Bracket br(c, K_FORCE);
-    hipLaunchKernelGGL(k_force<NOISE>, dim3(grid), dim3(kBlock), 0, c->stream, c->w, c->counters, c->x[1], c->y[1],
-                       c->vx[1], c->vy[1], c->id[1], c->wslotT, c->cellT, c->nbr, c->cnt, cap, c->eta, c->offById, c->P, c->sx,
-                       c->sy, c->wrec, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0]);
-  }
+void launch_pass_b(sc_ctx* c) {
+  Bracket br(c, K_FORCE);
+  hipLaunchKernelGGL(k_pass_b<NOISE>, dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters, c->x[1], c->y[1],
+                     c->vx[1], c->vy[1], c->id[1], c->wslotT, c->cellT, c->nbr, c->cnt, (int)c->cap, c->eta,
+                     c->offById, c->P, c->sx, c->sy, c->wrec, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], c->tileBounds);
 }
 
 }  // namespace
@@ -399,6 +405,7 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
   if (e == hipSuccess) e = dalloc(&c->perm, n);
   if (e == hipSuccess) e = dalloc(&c->keyX, n);
   if (e == hipSuccess) e = dalloc(&c->keyId, n);
+  if (e == hipSuccess) e = dalloc(&c->tileBounds, 6 * (n / kTileW + 2));
   if (e == hipSuccess) e = dalloc(&c->wrec, 5 * n);
   if (e == hipSuccess) e = dalloc(&c->nbr, (size_t)kMaxNbr * n);
   if (e == hipSuccess) e = dalloc(&c->cnt, n);
@@ -427,7 +434,7 @@ int sc_destroy(sc_ctx* c) {
     (void)hipFree(c->vy[s]);
     (void)hipFree(c->id[s]);
   }
-  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->cellCount, c->cellStart, c->blockSums, c->wrec,
+  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->cellCount, c->cellStart, c->blockSums, c->wrec,
                   c->nbr, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
                   c->stage_xy, c->stage_vxy, c->owned_out};
   for (void* p : ptrs)
@@ -559,12 +566,14 @@ int sc_step_begin(sc_ctx* c) {
                        c->cellS, c->cellStart, c->wslotS, c->y[0], c->vx[0], c->vy[0], c->x[1], c->y[1], c->vx[1],
                        c->vy[1], c->id[1], c->cellT, c->wslotT);
   }
-  {
-    Bracket br(c, K_NEIGHBORS);
-    int ngrid = (int)std::max<int64_t>(1, (launch_bound(c) + kNbrPerBlock - 1) / kNbrPerBlock);
-    hipLaunchKernelGGL(k_neighbors, dim3(ngrid), dim3(kBlock), 0, c->stream, w, c->counters, c->x[1], c->y[1], c->cellT,
-                       c->cellStart, c->nbr, c->cnt, cap);
-  }
+  // SC_NOISE_HOST (and the stand-alone search) stop after the lists: the host's rand block can only be
+  // indexed once every count is known.  Otherwise the search and pass A are one launch.
+  if (c->noise_mode == SC_NOISE_HOST || c->custom_grid)
+    launch_pass_a<SC_NOISE_NONE, true, false>(c, K_NEIGHBORS);
+  else if (c->noise_mode == SC_NOISE_COUNTER)
+    launch_pass_a<SC_NOISE_COUNTER, true, true>(c, K_PASS_A);
+  else
+    launch_pass_a<SC_NOISE_NONE, true, true>(c, K_PASS_A);
   if (c->noise_mode == SC_NOISE_HOST && c->next_id > 0) {
     rc = ensure_ids(c, c->next_id);
     if (rc) return rc;
@@ -618,12 +627,16 @@ int sc_step_finish(sc_ctx* c) {
   if (!c->in_step) return fail(SC_ERR_STATE, "sc_step_finish needs sc_step_begin first");
   if (c->noise_mode == SC_NOISE_HOST && c->etaPairs < 0)
     return fail(SC_ERR_STATE, "SC_NOISE_HOST: sc_set_noise_host must be called every tick");
-  int grid = grid_for(launch_bound(c));
-  int cap = (int)c->cap;
   switch (c->noise_mode) {
-    case SC_NOISE_HOST: launch_finish<SC_NOISE_HOST>(c, grid, cap); break;
-    case SC_NOISE_COUNTER: launch_finish<SC_NOISE_COUNTER>(c, grid, cap); break;
-    default: launch_finish<SC_NOISE_NONE>(c, grid, cap); break;
+    case SC_NOISE_HOST:
+      launch_pass_a<SC_NOISE_HOST, false, true>(c, K_DENSITY);
+      launch_pass_b<SC_NOISE_HOST>(c);
+      break;
+    case SC_NOISE_COUNTER: launch_pass_b<SC_NOISE_COUNTER>(c); break;
+    default:
+      if (c->custom_grid) launch_pass_a<SC_NOISE_NONE, false, true>(c, K_DENSITY);
+      launch_pass_b<SC_NOISE_NONE>(c);
+      break;
   }
   HIPCHK(hipGetLastError());
   c->in_step = false;
@@ -736,6 +749,9 @@ int sc_download_neighbors(sc_ctx* c, int64_t* ids, int32_t* counts, int64_t* nei
   std::vector<unsigned char> cnt(n);
   std::vector<double> hx(n), hy(n);
   std::vector<int> slot(n);
+  const int64_t nblocks = (n + kTileW - 1) / kTileW;
+  std::vector<int> tb(6 * std::max<int64_t>(nblocks, 1));
+  if ((rc = fetch(c, tb.data(), c->tileBounds, 6 * nblocks * sizeof(int)))) return rc;
   if ((rc = fetch(c, id.data(), c->id[1], n * sizeof(int))) || (rc = fetch(c, cnt.data(), c->cnt, n)) ||
       (rc = fetch(c, hx.data(), c->x[1], n * sizeof(double))) || (rc = fetch(c, hy.data(), c->y[1], n * sizeof(double))))
     return rc;
@@ -745,8 +761,12 @@ int sc_download_neighbors(sc_ctx* c, int64_t* ids, int32_t* counts, int64_t* nei
   for (int s = 0; s < kMaxNbr && neighbors; ++s) {
     if ((rc = fetch(c, slot.data(), c->nbr + (size_t)s * c->cap, n * sizeof(int)))) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
-    for (int64_t k = 0; k < n; ++k)
-      if (s < cnt[k]) neighbors[k * kMaxNbr + s] = id[slot[k]];
+    for (int64_t k = 0; k < n; ++k) {
+      if (s >= cnt[k]) continue;
+      const int* b = tb.data() + 6 * (k / kTileW);  // the table holds tile slots of the particle's block
+      const Tile tl{b[0], b[1] - b[0], b[2], b[3] - b[2], b[4], b[5] - b[4]};
+      neighbors[k * kMaxNbr + s] = id[entry_index(tl, slot[k])];
+    }
   }
   for (int64_t k = 0; k < n; ++k) {
     if (ids) ids[k] = id[k];

@@ -294,102 +294,10 @@ __global__ void __launch_bounds__(kBlock)
   wslotT[dst] = wsi;
 }
 
-// ------------------------------------------------------------------------------------------
-// K5  neighbor lists in the reference's canonical order (collision_detector.py:9-121):
-//   [same row, to the right, x ascending] [row+1, x ascending]
-//   [same row, to the left, x descending] [row-1, x descending], cut at 20.
-// In the (row, x, id)-sorted array each of the three rows' candidates (columns c-1..c+1) is one
-// contiguous range, so the canonical candidate sequence of particle i is four index runs:
-//   i+1 .. e0-1 | b1 .. e1-1 | i-1 .. b0 (down) | em-1 .. bm (down).
-// Sixteen lanes share one particle: each tests one candidate of the current 16-wide chunk, the
-// wave ballot of the predicate is cut into the group's 16 bits, and the popcount of the lower bits
-// is the lane's slot in the list (prefix-sum compaction); the running total stops the scan at 20.
-// The forward predicates are the reference's own (:106-119, :75-80); a reverse edge j->i exists
-// exactly when i is a forward candidate of j (:85-88).  A workgroup handles 64 particles, keeps
-// their lists in LDS and writes them slot-major (nbr[s*cap + i]) with coalesced stores.
-// ------------------------------------------------------------------------------------------
-constexpr int kNbrPerBlock = 64;
+// K5-K7 (neighbor search, pass A, pass B) are the LDS-tiled kernels of sc_tiled.h.
 
-__global__ void __launch_bounds__(kBlock)
-    k_neighbors(World w, int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
-                const int* __restrict__ cell, const int* __restrict__ cellStart, int* __restrict__ nbr,
-                unsigned char* __restrict__ cnt, int cap) {
-  __shared__ int list[kMaxNbr][kNbrPerBlock + 1];
-  __shared__ int counts[kNbrPerBlock];
-  const int n = counters[C_NT];
-  const int g = threadIdx.x & 15;          // lane inside the group
-  const int grp = threadIdx.x >> 4;        // group inside the workgroup (0..15)
-  const int shift = (threadIdx.x & 63) & ~15;  // where the group's bits sit in the wave ballot
-  const int i0 = blockIdx.x * kNbrPerBlock;
-  for (int round = 0; round < kNbrPerBlock / 16; ++round) {
-    const int local = round * 16 + grp;
-    const int i = i0 + local;
-    int base = 0;
-    if (i < n) {  // uniform inside the group
-      const int c = cell[i] & kCellMask;
-      const double xi = x[i], yi = y[i];
-      const double xhi = xi + w.d, xlo = xi - w.d;
-      const int e0 = cellStart[c + 2], b0 = cellStart[c - 1];
-      const int b1 = cellStart[c + w.ncols - 1], e1 = cellStart[c + w.ncols + 2];
-      const int bm = cellStart[c - w.ncols - 1], em = cellStart[c - w.ncols + 2];
-      const int n0 = e0 - (i + 1), n1 = e1 - b1, n2 = i - b0, n3 = em - bm;
-      const int total = n0 + n1 + n2 + n3;
-      for (int v0 = 0; v0 < total && base < kMaxNbr; v0 += 16) {
-        int v = v0 + g;
-        bool ok = false;
-        int j = 0;
-        if (v < total) {
-          int type;
-          if (v < n0) {
-            j = i + 1 + v;
-            type = 0;
-          } else if (v < n0 + n1) {
-            j = b1 + (v - n0);
-            type = 1;
-          } else if (v < n0 + n1 + n2) {
-            j = i - 1 - (v - n0 - n1);
-            type = 2;
-          } else {
-            j = em - 1 - (v - n0 - n1 - n2);
-            type = 3;
-          }
-          double xj = x[j], yj = y[j];
-          bool win;
-          if (type == 0) {
-            win = xj <= xhi;                       // searchsorted(strip_x, x_i + d, "right")      :106
-          } else if (type == 1) {
-            win = xj >= xlo && xj <= xhi;          // next strip window                           :112-113
-          } else if (type == 2) {
-            win = xi <= xj + w.d;                  // i is in j's same-strip window
-          } else {
-            win = xi >= xj - w.d && xi <= xj + w.d;  // i is in j's next-strip window
-          }
-          double dx = xj - xi, dy = yj - yi;
-          ok = win && (dx * dx + dy * dy <= w.t_nbr);  // norm(p_j - p_i) <= d                      :78-79
-        }
-        unsigned long long ballot = __ballot(ok);
-        unsigned mask = (unsigned)(ballot >> shift) & 0xFFFFu;
-        int slot = base + __popc(mask & ((1u << g) - 1u));
-        if (ok && slot < kMaxNbr) list[slot][local] = j;
-        base += __popc(mask);
-      }
-      if (base > kMaxNbr) base = kMaxNbr;
-    }
-    if (g == 0) counts[local] = base;
-  }
-  __syncthreads();
-  // coalesced write-out: thread t handles particle (t & 63), slots (t >> 6), +4, +8, ...
-  const int pl = threadIdx.x & 63;
-  const int ip = i0 + pl;
-  const int cp = ip < n ? counts[pl] : 0;
-  if (ip < n) {
-    for (int s = threadIdx.x >> 6; s < cp; s += kBlock / 64) nbr[(size_t)s * cap + ip] = list[s][pl];
-    if (threadIdx.x < 64) cnt[ip] = (unsigned char)cp;
-  }
-}
-
-// Sum and maximum of the neighbor counts, on demand (sc_step_stats).  Kept out of K5: one atomic
-// per workgroup on a single address serialises at ~12 ns each and dominated that kernel.
+// Sum and maximum of the neighbor counts, on demand (sc_step_stats).  Kept out of the search kernel:
+// one atomic per workgroup on a single address serialises at ~12 ns each and dominated it.
 __global__ void __launch_bounds__(kBlock) k_count_stats(int* __restrict__ counters, const unsigned char* __restrict__ cnt) {
   __shared__ int ssum[kBlock / 64], smax[kBlock / 64];
   int n = counters[C_NT];
@@ -445,175 +353,6 @@ __device__ __forceinline__ void collider_noise(const World& w, int id, int slot,
     ex = (ux - 0.5) * w.d * w.level;
     ey = (uy - 0.5) * w.d * w.level;
   }
-}
-
-// ------------------------------------------------------------------------------------------
-// K6  pass A "density + normals": populate_colliders (crate.py:161-175), compute_particle_pressures
-// (:261-275) and pass 1 of apply_tension (:337-342).  Writes P_i and s_i.
-// ------------------------------------------------------------------------------------------
-template <int NOISE>
-__global__ void __launch_bounds__(kBlock)
-    k_density(World w, const int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
-              const int* __restrict__ id, const int* __restrict__ nbr, const unsigned char* __restrict__ cnt, int cap,
-              const double* __restrict__ eta, const int* __restrict__ offById, double* __restrict__ P,
-              double* __restrict__ sx, double* __restrict__ sy) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= counters[C_NT]) return;
-  int C = cnt[i];
-  double xi = x[i], yi = y[i];
-  int idi = (NOISE == SC_NOISE_NONE) ? 0 : id[i];
-  int off = (NOISE == SC_NOISE_HOST) ? offById[idi] : 0;
-  double sumw = 0, ax = 0, ay = 0;
-  for (int s = 0; s < C; ++s) {
-    int j = nbr[(size_t)s * cap + i];
-    double ex, ey;
-    collider_noise<NOISE>(w, idi, s, eta, off, ex, ey);
-    double rx = xi - (x[j] + ex), ry = yi - (y[j] + ey);  // crate.py:167-171
-    double dist = sqrt(rx * rx + ry * ry);
-    double rinv = 1.0 / dist;
-    double nx = rx * rinv, ny = ry * rinv;                 // crate.py:174
-    double ov = 1 - clip01(dist * w.inv_d);                // crate.py:270
-    sumw += ov;
-    double t = (1 - ov) * ov;                              // crate.py:342
-    ax += t * nx;
-    ay += t * ny;
-  }
-  P[i] = C ? fmax(0.0, sumw - w.ignored) : 0.0;  // crate.py:265-273
-  sx[i] = ax;
-  sy[i] = ay;
-}
-
-// ------------------------------------------------------------------------------------------
-// K7  pass B "force + integrate", fused: pass 2 of apply_tension (crate.py:343-353), apply_gravity
-// (:309-310), apply_pressure (:295-307), apply_viscosity (:316-323), apply_wall_bounce (:245-259),
-// apply_continuous_collision_velocity_fix (:177-200; geometry_utils.py:136-143, :182-222) and
-// apply_particles_velocity (:360-361).  Reads the sorted arrays, writes the storage arrays in
-// the same (sorted) order: that is the next tick's input.
-// ------------------------------------------------------------------------------------------
-template <int NOISE>
-__global__ void __launch_bounds__(kBlock)
-    k_force(World w, int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
-            const double* __restrict__ vx, const double* __restrict__ vy, const int* __restrict__ id,
-            const int* __restrict__ wslot, const int* __restrict__ cell, const int* __restrict__ nbr,
-            const unsigned char* __restrict__ cnt, int cap,
-            const double* __restrict__ eta, const int* __restrict__ offById, const double* __restrict__ P,
-            const double* __restrict__ sx, const double* __restrict__ sy, const double* __restrict__ wrec,
-            double* __restrict__ xo, double* __restrict__ yo, double* __restrict__ vxo, double* __restrict__ vyo,
-            int* __restrict__ ido) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  int n = counters[C_NT];
-  if (i == 0) {
-    counters[C_NS] = n;  // the storage arrays now hold the n live particles
-    counters[C_WREC] = 0;  // per-tick counters start the next tick at zero (read by sc_step_stats
-    counters[C_SUMC] = 0;  // between sc_step_begin and sc_step_finish, i.e. before this kernel)
-    counters[C_SUMC_HI] = 0;
-    counters[C_MAXC] = 0;
-  }
-  if (i >= n) return;
-  if (w.slab && (cell[i] & kGhostBit)) {
-    // ghosts served as neighbors only; +inf makes next tick's removal test (crate.py:152) drop the copy
-    xo[i] = __builtin_huge_val();
-    yo[i] = 0.0;
-    vxo[i] = 0.0;
-    vyo[i] = 0.0;
-    ido[i] = -1;
-    return;
-  }
-  int C = cnt[i];
-  double xi = x[i], yi = y[i];
-  double vxi = vx[i], vyi = vy[i];
-  double Pi = P[i], sxi = sx[i], syi = sy[i];
-  int idi = id[i];
-  int off = (NOISE == SC_NOISE_HOST) ? offById[idi] : 0;
-  double tx = 0, ty = 0, qx = 0, qy = 0, ux = 0, uy = 0;
-  for (int s = 0; s < C; ++s) {
-    int j = nbr[(size_t)s * cap + i];
-    double ex, ey;
-    collider_noise<NOISE>(w, idi, s, eta, off, ex, ey);
-    double rx = xi - (x[j] + ex), ry = yi - (y[j] + ey);
-    double rinv = 1.0 / sqrt(rx * rx + ry * ry);
-    double nx = rx * rinv, ny = ry * rinv;
-    double Pj = P[j];
-    double align = ((sxi - sx[j]) * nx + (syi - sy[j]) * ny) * w.ss;  // crate.py:347-349
-    double fix = Pj + Pi - 2 * w.tp;                                   // crate.py:351
-    double k = align + fix;
-    tx += k * nx;
-    ty += k * ny;
-    double pp = Pi + Pj;  // crate.py:301-304
-    qx += nx * pp;
-    qy += ny * pp;
-    ux += vx[j];  // crate.py:175 snapshot of the neighbors' start-of-tick velocities
-    uy += vy[j];
-  }
-  vxi += w.dt * tx;  // crate.py:352
-  vyi += w.dt * ty;
-  vxi += w.dt * w.gx;  // crate.py:310
-  vyi += w.dt * w.gy;
-  int ws = wslot[i];
-  double Ux = 0, Uy = 0, Cx = 0, Cy = 0, V = 0;
-  if (ws >= 0) {
-    const double* rec = wrec + 5 * (size_t)ws;
-    Ux = rec[0];
-    Uy = rec[1];
-    Cx = rec[2];
-    Cy = rec[3];
-    V = rec[4];
-    qx += Ux * Pi;  // wall colliders carry pressure 0 and are not normalised (crate.py:286-293)
-    qy += Uy * Pi;
-  }
-  double dpa = w.dt * w.pamp;
-  vxi += dpa * qx;  // crate.py:306
-  vyi += dpa * qy;
-  double dv = w.dt * w.visc;  // crate.py:319-323: sum_j (v0_j - v_i) with v_i the current velocity
-  vxi += dv * (ux - C * vxi);
-  vyi += dv * (uy - C * vyi);
-  if (ws >= 0) {  // crate.py:245-259
-    double nx = Ux / V, ny = Uy / V;
-    double nn = sqrt(nx * nx + ny * ny);
-    nx /= nn;
-    ny /= nn;
-    double cvx = Cx / V, cvy = Cy / V;
-    double q = (vxi - cvx) * nx + (vyi - cvy) * ny;
-    if (q < 0) {
-      double cx = -1 * q * nx, cy = -1 * q * ny;
-      vxi += cx;
-      vyi += cy;
-      vxi += cx * w.decay;
-      vyi += cy * w.decay;
-    }
-  }
-  // continuous collision: movement p -> p + v*dt against the 2S padded segments
-  double mx = vxi * w.dt, my = vyi * w.dt;
-  if (!(ws == -1 && mx * mx + my * my < w.ccd_skip2)) {
-    double bx = xi + mx, by = yi + my;   // crate.py:183-184
-    double abx = bx - xi, aby = by - yi;  // geometry_utils.py:205 uses (b - a)
-    double fac = 1.0;
-    for (int m = 0; m < 2 * w.nseg; ++m) {
-      Seg s = w.pad[m];
-      double dcx = s.bx - s.ax, dcy = s.by - s.ay;
-      if (!(dcy * abx + (-dcx) * aby < 0)) continue;  // opposite_direction_map (:205)
-      // orientation(p,q,r) = sign((q.y-p.y)*(r.x-q.x) - (q.x-p.x)*(r.y-q.y))  (:212-222)
-      double o1 = (by - yi) * (s.ax - bx) - (bx - xi) * (s.ay - by);  // (a,b,c)
-      double o2 = (by - yi) * (s.bx - bx) - (bx - xi) * (s.by - by);  // (a,b,d)
-      double o3 = (s.by - s.ay) * (xi - s.bx) - (s.bx - s.ax) * (yi - s.by);  // (c,d,a)
-      double o4 = (s.by - s.ay) * (bx - s.bx) - (s.bx - s.ax) * (by - s.by);  // (c,d,b)
-      int g1 = (o1 > 0) - (o1 < 0), g2 = (o2 > 0) - (o2 < 0), g3 = (o3 > 0) - (o3 < 0), g4 = (o4 > 0) - (o4 < 0);
-      bool n1 = o1 != o1, n2 = o2 != o2, n3 = o3 != o3, n4 = o4 != o4;  // np.sign(nan) = nan, nan != x
-      if ((g1 != g2 || n1 || n2) && (g3 != g4 || n3 || n4)) {
-        // calc_collision_point(a, ab = v*dt, c, cd): cross(a-c, cd) / cross(cd, ab)  (:141-143)
-        double acx = xi - s.ax, acy = yi - s.ay;
-        double f = (acx * dcy - acy * dcx) / (dcx * my - dcy * mx);
-        if (f < fac) fac = f;  // crate.py:198-199
-      }
-    }
-    vxi *= fac;  // crate.py:200
-    vyi *= fac;
-  }
-  xo[i] = xi + w.dt * vxi;  // crate.py:361
-  yo[i] = yi + w.dt * vyi;
-  vxo[i] = vxi;
-  vyo[i] = vyi;
-  ido[i] = idi;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,518 @@
+// LDS-tiled pass A (neighbor search + density + surface normals) and pass B (forces + integration)
+// for gfx950.  Included once by sandcrate_hip.hip after sc_kernels.h.
+//
+// Geometry.  The sorted arrays are in (row, x, id) order and cells are numbered row-major with a
+// ring of empty cells, so for a block of kTileW consecutive particles (cells c_first..c_last) the
+// candidates of ALL its particles lie in three contiguous index ranges:
+//     same rows      [cellStart[c_first - 1],         cellStart[c_last + 2])
+//     next rows      [cellStart[c_first + ncols - 1], cellStart[c_last + ncols + 2])
+//     previous rows  [cellStart[c_first - ncols - 1], cellStart[c_last - ncols + 2])
+// (about 3 x (kTileW + 12) particles at 3.8 particles per cell).  A workgroup copies these ranges
+// into LDS once with coalesced loads; every later read of a neighbor is a ds_read.  Positions in
+// the concatenation of the three ranges are "tile slots"; the neighbor table stores tile slots, so
+// pass B, which stages the same three ranges (pass A publishes them per block), indexes its tile
+// directly.  A tile that does not fit the LDS budget (a block inside a very dense region) is read
+// from global memory by a second instantiation of the same body behind one workgroup-uniform branch
+// -- two instantiations rather than one body with a run-time flag, because a run-time choice
+// between an LDS and a global address compiles to flat loads.
+//
+// What bounds these kernels (rocprofv3 counters, profiles/): with 262,144 particles every kernel
+// starts with a cold L2 (multi-XCD coherence at kernel boundaries) and a wave's time is a chain of
+// dependent cold misses, ~2 us each, plus fp64 VALU issue (wave64 fp64 instructions take 4 cycles);
+// from ~1M particles on it is fp64 VALU issue alone.  Hence: loads that do not depend on each other
+// are issued together ahead of the first wait, one thread scans its candidates serially from LDS
+// (about 12 instructions per candidate), and the pair math uses v_rsq_f64 + Newton steps instead of
+// an IEEE sqrt and divide.
+#pragma once
+#include "sc_kernels.h"
+
+namespace sc {
+
+constexpr int kTileW = 128;      // particles (= threads) per workgroup
+constexpr int kTileCapA = 512;   // pass A tile: (x, y) records, 8 KiB
+constexpr int kTileCapB = 480;   // pass B tile: (x, y, vx, vy, P, sx, sy, -) records, 30 KiB
+constexpr int kSlotMax = 65535;  // lists are staged as u16 tile slots in pass A
+
+struct Tile {
+  int a0, n0;  // same rows
+  int a1, n1;  // next rows
+  int a2, n2;  // previous rows
+};
+
+__device__ __host__ __forceinline__ int tile_index(const Tile& t, int slot) {  // tile slot -> sorted index
+  if (slot < t.n0) return t.a0 + slot;
+  slot -= t.n0;
+  if (slot < t.n1) return t.a1 + slot;
+  return t.a2 + (slot - t.n1);
+}
+
+// A neighbor-table entry is a tile slot (>= 0) or, for a tile too large for u16 slots, -(index+1).
+__device__ __host__ __forceinline__ int entry_index(const Tile& t, int e) { return e >= 0 ? tile_index(t, e) : -e - 1; }
+
+// 1/sqrt(s) to about 1 ulp: hardware estimate + two Newton steps (explicit fma; nothing here
+// feeds a decision).  s = 0 gives NaN downstream, like the reference's 0/0 (crate.py:174).
+__device__ __forceinline__ double rsqrt_nr(double s) {
+  double y = __builtin_amdgcn_rsq(s);
+  const double h = 0.5 * s;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  return y;
+}
+
+struct XY {
+  double x, y;
+};
+
+// Phases 3-5 of pass A for one particle.  LDS: where the tile is (compile time, see the header).
+template <int NOISE, bool ENUM, bool DENS, bool LDS>
+__device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, const int total, const XY* txy,
+                                            unsigned short (*list)[kTileW + 2], const int t, const int i,
+                                            const bool live, const int idi, const int e0, const int b0, const int b1,
+                                            const int e1, const int bm, const int em, const double* __restrict__ x,
+                                            const double* __restrict__ y, int* __restrict__ nbr,
+                                            unsigned char* __restrict__ cnt, const int cap,
+                                            const double* __restrict__ eta, const int* __restrict__ offById,
+                                            double* __restrict__ P, double* __restrict__ sx, double* __restrict__ sy) {
+  auto load_xy = [&](int slot) -> XY {
+    if constexpr (LDS) {
+      return txy[slot];
+    } else {
+      const int j = tile_index(tl, slot);
+      return XY{x[j], y[j]};
+    }
+  };
+  const bool slots_fit = total <= kSlotMax;
+
+  // 3. neighbor list of particle i: four serial scans in the reference's order, entries are tile slots
+  int C = 0;
+  const int self = i - tl.a0;
+  XY pi{0, 0};
+  if (live) pi = load_xy(self);
+  if (ENUM) {
+    if (live && slots_fit) {
+      const double xi = pi.x, yi = pi.y;
+      const double xhi = xi + w.d, xlo = xi - w.d;
+      // one scan: `count` candidates from tile slot `first`, walking by `step`; window() says
+      // 0 = stop the scan, 1 = outside the window, 2 = inside
+      auto scan = [&](int first, int count, int step, auto window) {
+        int slot = first;
+        for (int v = 0; v < count; ++v, slot += step) {
+          const XY q = load_xy(slot);
+          const int verdict = window(q.x);
+          if (verdict == 0) break;
+          if (verdict == 2) {
+            const double dx = q.x - xi, dy = q.y - yi;
+            if (dx * dx + dy * dy <= w.t_nbr) {  // norm(p_j - p_i) <= d (collision_detector.py:78-79)
+              list[C][t] = (unsigned short)slot;
+              if (++C == kMaxNbr) break;         // trim (:91-93)
+            }
+          }
+        }
+      };
+      // same strip, after i: x_j <= x_i + d                                  (:106-109)
+      scan(self + 1, e0 - (i + 1), 1, [&](double xj) { return xj > xhi ? 0 : 2; });
+      // next strip: x_i - d <= x_j <= x_i + d                                (:112-119)
+      if (C < kMaxNbr) scan(tl.n0 + (b1 - tl.a1), e1 - b1, 1, [&](double xj) { return xj > xhi ? 0 : (xj >= xlo ? 2 : 1); });
+      // reverse edges (:85-88): i is a forward candidate of j, same strip
+      if (C < kMaxNbr) scan(self - 1, i - b0, -1, [&](double xj) { return !(xi <= xj + w.d) ? 0 : 2; });
+      // reverse edges from the previous strip
+      if (C < kMaxNbr)
+        scan(tl.n0 + tl.n1 + (em - 1 - tl.a2), em - bm, -1,
+             [&](double xj) { return !(xi <= xj + w.d) ? 0 : (xi >= xj - w.d ? 2 : 1); });
+    } else if (live) {
+      // a tile beyond 65535 particles (a block inside one gigantic bucket) cannot use u16 slots:
+      // entries go straight to the table as -(index+1); correctness path only
+      const double xi = pi.x, yi = pi.y;
+      const double xhi = xi + w.d, xlo = xi - w.d;
+      auto push = [&](int j) { nbr[(size_t)C++ * cap + i] = -j - 1; };
+      for (int j = i + 1; j < e0 && C < kMaxNbr; ++j) {
+        const double xj = x[j];
+        if (xj > xhi) break;
+        const double dx = xj - xi, dy = y[j] - yi;
+        if (dx * dx + dy * dy <= w.t_nbr) push(j);
+      }
+      for (int j = b1; j < e1 && C < kMaxNbr; ++j) {
+        const double xj = x[j];
+        if (xj > xhi) break;
+        if (xj >= xlo) {
+          const double dx = xj - xi, dy = y[j] - yi;
+          if (dx * dx + dy * dy <= w.t_nbr) push(j);
+        }
+      }
+      for (int j = i - 1; j >= b0 && C < kMaxNbr; --j) {
+        const double xj = x[j];
+        if (!(xi <= xj + w.d)) break;
+        const double dx = xj - xi, dy = y[j] - yi;
+        if (dx * dx + dy * dy <= w.t_nbr) push(j);
+      }
+      for (int j = em - 1; j >= bm && C < kMaxNbr; --j) {
+        const double xj = x[j];
+        if (!(xi <= xj + w.d)) break;
+        if (xi >= xj - w.d) {
+          const double dx = xj - xi, dy = y[j] - yi;
+          if (dx * dx + dy * dy <= w.t_nbr) push(j);
+        }
+      }
+    }
+  } else if (live) {
+    // lists were built by an earlier launch: bring them in (coalesced, slot-major)
+    C = cnt[i];
+    if (slots_fit)
+      for (int s = 0; s < C; ++s) list[s][t] = (unsigned short)nbr[(size_t)s * cap + i];
+  }
+
+  // 4. pair math of pass A: populate_colliders (crate.py:161-175), pressures (:261-275), normals (:337-342)
+  if (DENS && live) {
+    double sumw = 0, ax = 0, ay = 0;
+    const int off = (NOISE == SC_NOISE_HOST) ? offById[idi] : 0;
+    for (int s = 0; s < C; ++s) {
+      XY q;
+      if (slots_fit) {
+        q = load_xy((int)list[s][t]);
+      } else {
+        const int j = -nbr[(size_t)s * cap + i] - 1;
+        q = XY{x[j], y[j]};
+      }
+      double ex, ey;
+      collider_noise<NOISE>(w, idi, s, eta, off, ex, ey);
+      const double rx = pi.x - (q.x + ex), ry = pi.y - (q.y + ey);  // crate.py:167-171
+      const double s2 = rx * rx + ry * ry;
+      const double rinv = rsqrt_nr(s2);
+      const double dist = s2 * rinv;
+      const double nx = rx * rinv, ny = ry * rinv;   // crate.py:174
+      const double ov = 1 - clip01(dist * w.inv_d);  // crate.py:270
+      sumw += ov;
+      const double tt = (1 - ov) * ov;               // crate.py:342
+      ax += tt * nx;
+      ay += tt * ny;
+    }
+    P[i] = C ? fmax(0.0, sumw - w.ignored) : 0.0;  // crate.py:265-273
+    sx[i] = ax;
+    sy[i] = ay;
+  }
+
+  // 5. lists out, slot-major: for a fixed slot consecutive threads write consecutive words
+  if (ENUM && live) {
+    if (slots_fit)
+      for (int s = 0; s < C; ++s) nbr[(size_t)s * cap + i] = (int)list[s][t];
+    cnt[i] = (unsigned char)C;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Pass A.  ENUM: build the neighbor lists in the reference's canonical order
+//   [same row, to the right, x ascending] [row+1, x ascending]
+//   [same row, to the left, x descending] [row-1, x descending], cut at 20
+// (collision_detector.py:9-121: forward candidates :106-119 with the distance filter :75-80, a
+// reverse edge j->i exists exactly when i is a forward candidate of j :85-88, trim :91-93) and
+// write them slot-major with the counts.  DENS: populate_colliders (crate.py:161-175),
+// compute_particle_pressures (:261-275) and pass 1 of apply_tension (:337-342) -> P, sx, sy.
+// One launch does both, except in SC_NOISE_HOST mode where the host's noise block can only be
+// indexed after all counts are known: then <ENUM only> runs in sc_step_begin and <DENS only> in
+// sc_step_finish.
+// ------------------------------------------------------------------------------------------
+template <int NOISE, bool ENUM, bool DENS>
+__global__ void __launch_bounds__(kTileW)
+    k_pass_a(World w, const int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
+             const int* __restrict__ id, const int* __restrict__ cell, const int* __restrict__ cellStart,
+             int* __restrict__ nbr, unsigned char* __restrict__ cnt, int cap, const double* __restrict__ eta,
+             const int* __restrict__ offById, double* __restrict__ P, double* __restrict__ sx,
+             double* __restrict__ sy, int* __restrict__ tileBounds) {
+  __shared__ XY txy[kTileCapA];
+  __shared__ unsigned short list[kMaxNbr][kTileW + 2];  // tile slots of the neighbors, [slot][thread]
+  __shared__ int bounds[6];
+
+  const int t = threadIdx.x;
+  const int i0 = blockIdx.x * kTileW;
+  const int i = i0 + t;
+  // everything that does not depend on the live count is requested before the count is waited for
+  const int ic = min(i, cap - 1);
+  const int cpacked = cell[ic];
+  const int idi = (DENS && NOISE != SC_NOISE_NONE) ? id[ic] : 0;
+  const int n = counters[C_NT];
+  if (i0 >= n) return;
+  const int m = min(kTileW, n - i0);
+  const bool live = t < m;
+
+  // 1. own candidate ranges (cell -> six bucket boundaries); first / last thread publish the tile
+  int e0 = 0, b0 = 0, b1 = 0, e1 = 0, bm = 0, em = 0;
+  if (live) {
+    const int c = cpacked & kCellMask;
+    e0 = cellStart[c + 2];
+    b0 = cellStart[c - 1];
+    b1 = cellStart[c + w.ncols - 1];
+    e1 = cellStart[c + w.ncols + 2];
+    bm = cellStart[c - w.ncols - 1];
+    em = cellStart[c - w.ncols + 2];
+    if (t == 0) {
+      bounds[0] = b0;
+      bounds[2] = b1;
+      bounds[4] = bm;
+    }
+    if (t == m - 1) {
+      bounds[1] = e0;
+      bounds[3] = e1;
+      bounds[5] = em;
+    }
+  }
+  __syncthreads();
+  Tile tl;
+  tl.a0 = bounds[0];
+  tl.n0 = bounds[1] - tl.a0;
+  tl.a1 = bounds[2];
+  tl.n1 = bounds[3] - tl.a1;
+  tl.a2 = bounds[4];
+  tl.n2 = bounds[5] - tl.a2;
+  const int total = tl.n0 + tl.n1 + tl.n2;
+  const bool in_lds = total <= kTileCapA;
+
+  // 2. stage (x, y) of the three ranges; every load of the tile is in flight before the first LDS write
+  if (in_lds) {
+    constexpr int kPer = kTileCapA / kTileW;
+    XY r[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int s = t + k * kTileW;
+      if (s < total) {
+        const int j = tile_index(tl, s);
+        r[k] = XY{x[j], y[j]};
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int s = t + k * kTileW;
+      if (s < total) txy[s] = r[k];
+    }
+  }
+  __syncthreads();
+  if (ENUM && t < 6) tileBounds[6 * blockIdx.x + t] = bounds[t];  // pass B stages the same three ranges
+
+  if (in_lds)
+    pass_a_body<NOISE, ENUM, DENS, true>(w, tl, total, txy, list, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr, cnt,
+                                         cap, eta, offById, P, sx, sy);
+  else
+    pass_a_body<NOISE, ENUM, DENS, false>(w, tl, total, txy, list, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr,
+                                          cnt, cap, eta, offById, P, sx, sy);
+}
+
+// ------------------------------------------------------------------------------------------
+// Pass B "force + integrate": pass 2 of apply_tension (crate.py:343-353), apply_gravity (:309-310),
+// apply_pressure (:295-307), apply_viscosity (:316-323), apply_wall_bounce (:245-259),
+// apply_continuous_collision_velocity_fix (:177-200; geometry_utils.py:136-143, :182-222) and
+// apply_particles_velocity (:360-361).  Reads the sorted arrays (through the LDS tile), writes the
+// storage arrays in the same order: that is the next tick's input.
+// ------------------------------------------------------------------------------------------
+struct Rec {
+  double x, y, vx, vy, P, sx, sy, pad;
+};
+
+// Phases 3-4 of pass B for one particle.  LDS: where the tile is (compile time, see the header).
+// js[] are neighbor-table entries (tile slots, or -(index+1)); `self` is the particle's own slot.
+template <int NOISE, bool LDS>
+__device__ __forceinline__ void pass_b_body(const World& w, const Tile& tl, const Rec* tile, const int i, const int self,
+                                            const int C, const int Cn, const int ws, const int idi,
+                                            const int (&js)[kMaxNbr], const double* __restrict__ x,
+                                            const double* __restrict__ y, const double* __restrict__ vx,
+                                            const double* __restrict__ vy, const double* __restrict__ eta,
+                                            const int* __restrict__ offById, const double* __restrict__ P,
+                                            const double* __restrict__ sx, const double* __restrict__ sy,
+                                            const double* __restrict__ wrec, double* __restrict__ xo,
+                                            double* __restrict__ yo, double* __restrict__ vxo, double* __restrict__ vyo,
+                                            int* __restrict__ ido) {
+  auto load_rec = [&](int e) -> Rec {
+    if constexpr (LDS) {
+      return tile[e];
+    } else {
+      const int j = entry_index(tl, e);
+      return Rec{x[j], y[j], vx[j], vy[j], P[j], sx[j], sy[j], 0.0};
+    }
+  };
+
+  // 3. pair math
+  const Rec me = load_rec(self);
+  const double xi = me.x, yi = me.y, Pi = me.P, sxi = me.sx, syi = me.sy;
+  double vxi = me.vx, vyi = me.vy;
+  const int off = (NOISE == SC_NOISE_HOST) ? offById[idi] : 0;
+  double tx = 0, ty = 0, qx = 0, qy = 0, ux = 0, uy = 0;
+#pragma unroll
+  for (int s = 0; s < kMaxNbr; ++s) {
+    if (s < Cn) {
+      const Rec o = load_rec(js[s]);
+      double ex, ey;
+      collider_noise<NOISE>(w, idi, s, eta, off, ex, ey);
+      const double rx = xi - (o.x + ex), ry = yi - (o.y + ey);
+      const double rinv = rsqrt_nr(rx * rx + ry * ry);
+      const double nx = rx * rinv, ny = ry * rinv;
+      const double align = ((sxi - o.sx) * nx + (syi - o.sy) * ny) * w.ss;  // crate.py:347-349
+      const double fix = o.P + Pi - 2 * w.tp;                                // crate.py:351
+      const double kk = align + fix;
+      tx += kk * nx;
+      ty += kk * ny;
+      const double pp = Pi + o.P;  // crate.py:301-304
+      qx += nx * pp;
+      qy += ny * pp;
+      ux += o.vx;  // crate.py:175: the neighbors' start-of-tick velocities
+      uy += o.vy;
+    }
+  }
+
+  // 4. per-particle epilogue
+  vxi += w.dt * tx;  // crate.py:352
+  vyi += w.dt * ty;
+  vxi += w.dt * w.gx;  // crate.py:310
+  vyi += w.dt * w.gy;
+  double Ux = 0, Uy = 0, Cx = 0, Cy = 0, V = 0;
+  if (ws >= 0) {
+    const double* rec = wrec + 5 * (size_t)ws;
+    Ux = rec[0]; Uy = rec[1]; Cx = rec[2]; Cy = rec[3]; V = rec[4];
+    qx += Ux * Pi;  // wall colliders carry pressure 0 and are not normalised (crate.py:286-293)
+    qy += Uy * Pi;
+  }
+  const double dpa = w.dt * w.pamp;
+  vxi += dpa * qx;  // crate.py:306
+  vyi += dpa * qy;
+  const double dv = w.dt * w.visc;  // crate.py:319-323: sum_j (v0_j - v_i), v_i the current velocity
+  vxi += dv * (ux - C * vxi);
+  vyi += dv * (uy - C * vyi);
+  if (ws >= 0) {  // crate.py:245-259
+    double nx = Ux / V, ny = Uy / V;
+    const double nn = sqrt(nx * nx + ny * ny);
+    nx /= nn;
+    ny /= nn;
+    const double cvx = Cx / V, cvy = Cy / V;
+    const double qq = (vxi - cvx) * nx + (vyi - cvy) * ny;
+    if (qq < 0) {
+      const double cx = -1 * qq * nx, cy = -1 * qq * ny;
+      vxi += cx;
+      vyi += cy;
+      vxi += cx * w.decay;
+      vyi += cy * w.decay;
+    }
+  }
+  // continuous collision: movement p -> p + v*dt against the 2S padded segments
+  const double mx = vxi * w.dt, my = vyi * w.dt;
+  if (!(ws == -1 && mx * mx + my * my < w.ccd_skip2)) {
+    const double bx = xi + mx, by = yi + my;    // crate.py:183-184
+    const double abx = bx - xi, aby = by - yi;  // geometry_utils.py:205 uses (b - a)
+    double fac = 1.0;
+    for (int mm = 0; mm < 2 * w.nseg; ++mm) {
+      const Seg s = w.pad[mm];
+      const double dcx = s.bx - s.ax, dcy = s.by - s.ay;
+      if (!(dcy * abx + (-dcx) * aby < 0)) continue;  // opposite_direction_map (:205)
+      // orientation(p,q,r) = sign((q.y-p.y)*(r.x-q.x) - (q.x-p.x)*(r.y-q.y))  (:212-222)
+      const double o1 = (by - yi) * (s.ax - bx) - (bx - xi) * (s.ay - by);          // (a,b,c)
+      const double o2 = (by - yi) * (s.bx - bx) - (bx - xi) * (s.by - by);          // (a,b,d)
+      const double o3 = (s.by - s.ay) * (xi - s.bx) - (s.bx - s.ax) * (yi - s.by);  // (c,d,a)
+      const double o4 = (s.by - s.ay) * (bx - s.bx) - (s.bx - s.ax) * (by - s.by);  // (c,d,b)
+      const int g1 = (o1 > 0) - (o1 < 0), g2 = (o2 > 0) - (o2 < 0), g3 = (o3 > 0) - (o3 < 0), g4 = (o4 > 0) - (o4 < 0);
+      const bool n1 = o1 != o1, n2 = o2 != o2, n3 = o3 != o3, n4 = o4 != o4;  // np.sign(nan) = nan, nan != x
+      if ((g1 != g2 || n1 || n2) && (g3 != g4 || n3 || n4)) {
+        // calc_collision_point(a, ab = v*dt, c, cd): cross(a-c, cd) / cross(cd, ab)  (:141-143)
+        const double acx = xi - s.ax, acy = yi - s.ay;
+        const double f = (acx * dcy - acy * dcx) / (dcx * my - dcy * mx);
+        if (f < fac) fac = f;  // crate.py:198-199
+      }
+    }
+    vxi *= fac;  // crate.py:200
+    vyi *= fac;
+  }
+  xo[i] = xi + w.dt * vxi;  // crate.py:361
+  yo[i] = yi + w.dt * vyi;
+  vxo[i] = vxi;
+  vyo[i] = vyi;
+  ido[i] = idi;
+}
+
+template <int NOISE>
+__global__ void __launch_bounds__(kTileW)
+    k_pass_b(World w, int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
+             const double* __restrict__ vx, const double* __restrict__ vy, const int* __restrict__ id,
+             const int* __restrict__ wslot, const int* __restrict__ cell, const int* __restrict__ nbr,
+             const unsigned char* __restrict__ cnt, int cap, const double* __restrict__ eta,
+             const int* __restrict__ offById, const double* __restrict__ P, const double* __restrict__ sx,
+             const double* __restrict__ sy, const double* __restrict__ wrec, double* __restrict__ xo,
+             double* __restrict__ yo, double* __restrict__ vxo, double* __restrict__ vyo, int* __restrict__ ido,
+             const int* __restrict__ tileBounds) {
+  __shared__ Rec tile[kTileCapB];
+
+  const int t = threadIdx.x;
+  const int i0 = blockIdx.x * kTileW;
+  const int i = i0 + t;
+  // 1. one round trip: the three ranges (published by pass A for this very block), the particle's
+  // scalars and all twenty table entries -- none of these loads waits for another
+  const int ic = min(i, cap - 1);
+  const int* tb = tileBounds + 6 * blockIdx.x;
+  const int tb0 = tb[0], tb1 = tb[1], tb2 = tb[2], tb3 = tb[3], tb4 = tb[4], tb5 = tb[5];
+  const int cpacked = cell[ic];
+  const int Craw = cnt[ic];
+  const int ws_raw = wslot[ic];
+  const int idi = id[ic];
+  int js[kMaxNbr];
+#pragma unroll
+  for (int s = 0; s < kMaxNbr; ++s) js[s] = nbr[(size_t)s * cap + ic];
+  const int n = counters[C_NT];
+  if (blockIdx.x == 0 && t == 0) {
+    counters[C_NS] = n;    // the storage arrays now hold the n live particles
+    counters[C_WREC] = 0;  // per-tick counters start the next tick at zero (sc_step_stats reads them
+    counters[C_SUMC] = 0;  // between sc_step_begin and sc_step_finish, i.e. before this kernel)
+    counters[C_SUMC_HI] = 0;
+    counters[C_MAXC] = 0;
+  }
+  if (i0 >= n) return;
+  const int m = min(kTileW, n - i0);
+  const bool live = t < m;
+
+  Tile tl;
+  tl.a0 = tb0;
+  tl.n0 = tb1 - tb0;
+  tl.a1 = tb2;
+  tl.n1 = tb3 - tb2;
+  tl.a2 = tb4;
+  tl.n2 = tb5 - tb4;
+  const int total = tl.n0 + tl.n1 + tl.n2;
+  const bool in_lds = total <= kTileCapB;
+  const bool ghost = w.slab && (cpacked & kGhostBit);
+  const int C = live ? Craw : 0;
+  const int Cn = ghost ? 0 : C;  // ghosts serve as neighbors only
+  const int ws = live ? ws_raw : -1;
+
+  // 2. stage the seven arrays of the three ranges as interleaved records; every load of the
+  // tile is in flight before the first LDS write
+  if (in_lds) {
+    constexpr int kPer = (kTileCapB + kTileW - 1) / kTileW;
+    Rec r[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int s = t + k * kTileW;
+      if (s < total) {
+        const int j = tile_index(tl, s);
+        r[k] = Rec{x[j], y[j], vx[j], vy[j], P[j], sx[j], sy[j], 0.0};
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int s = t + k * kTileW;
+      if (s < total) tile[s] = r[k];
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+
+  if (ghost) {
+    xo[i] = __builtin_huge_val();  // +inf: next tick's removal test (crate.py:152) drops the copy
+    yo[i] = 0.0;
+    vxo[i] = 0.0;
+    vyo[i] = 0.0;
+    ido[i] = -1;
+    return;
+  }
+  const int self = i - tl.a0;
+  if (in_lds)
+    pass_b_body<NOISE, true>(w, tl, tile, i, self, C, Cn, ws, idi, js, x, y, vx, vy, eta, offById, P, sx, sy, wrec, xo, yo,
+                             vxo, vyo, ido);
+  else
+    pass_b_body<NOISE, false>(w, tl, tile, i, self, C, Cn, ws, idi, js, x, y, vx, vy, eta, offById, P, sx, sy, wrec, xo,
+                              yo, vxo, vyo, ido);
+}
+
+}  // namespace sc

@@ -250,9 +250,10 @@ def tick_cases():
 # ---------------------------------------------------------------- G4 trajectories
 # The scenes are chaotic: a 1e-17 difference in summation order grows ~10x every 6-8 ticks
 # (measured: stirring_cup reaches 2e-3 by tick 94, wave_machine 1e-7 by tick 137), so the
-# horizons below are where any faithful float64 implementation still agrees to <1e-9.
+# horizons below are where faithful float64 implementations (differing by a few ulp per pair term)
+# still agree to well inside 1e-5 relative.
 def trajectory_cases():
-    for yaml_name, ticks in (("stirring_cup.yaml", (1, 10, 30, 60)), ("wave_machine.yaml", (1, 10, 50, 120))):
+    for yaml_name, ticks in (("stirring_cup.yaml", (1, 10, 30, 60)), ("wave_machine.yaml", (1, 10, 50, 100))):
         cfg = load_config(REF / "config" / yaml_name)
         crate = Crate(cfg.world_config)
         out = {}
