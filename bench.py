@@ -45,6 +45,21 @@ TICK_BYTES = 244
 FORCE_BYTES = 128
 
 
+def measured_traffic(particles_per_gpu: int, kernel: str):
+    """HBM-side bytes per launch of `kernel` from the rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs, calibrated on a float64 copy: scripts/collect_traffic.sh -> profiles/r01_traffic_<N>.json).
+    bench.py cannot collect hardware counters itself; it reports the committed measurement of the same
+    workload, or None when there is none for this size."""
+    path = ROOT / "profiles" / f"r01_traffic_{particles_per_gpu}.json"
+    if not path.exists():
+        return None, None
+    data = json.loads(path.read_text())
+    k = data["kernels"].get(kernel)
+    if not k:
+        return None, None
+    return k["traffic_bytes"], f"profiles/{path.name}: {data['source']}; {data['note']}"
+
+
 def synthetic_state(n: int, seed: int = 1234):
     rs = np.random.RandomState(seed)
     p = rs.rand(n, 2) * 0.96 + 0.02
@@ -203,9 +218,13 @@ def main() -> None:
         tick_us = sum(k["avg_us"] for k in kernels.values())
         pass_a = "neighbors_density" if "neighbors_density" in kernels else "density"
         force_us = kernels[pass_a]["avg_us"] + kernels["force_integrate"]["avg_us"]
+        traffic, traffic_src = measured_traffic(per_gpu, dom)
         roofline = {
             "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS, 5), "traffic": None,
+            "unit": "GB/s", "frac": round(kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS, 5), "traffic": traffic,
+            "traffic_source": traffic_src,
+            "note": "this path is not HBM bound on MI355X: at this size kernels are chains of cold-L2 misses plus "
+                    "fp64 VALU issue, from ~1M particles on fp64 VALU issue alone (DESIGN.md section 6)",
             "measured_over": f"a replay of the same {args.warmup}+{args.steps} ticks from the same initial state right after the timed region, HIP events around every launch",
             "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * per_gpu,
             "avg_launch_us": kernels[dom]["avg_us"],

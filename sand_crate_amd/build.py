@@ -12,7 +12,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 SRC = PKG / "csrc" / "sandcrate_hip.hip"
-DEPS = [SRC, PKG / "csrc" / "sc_kernels.h", PKG / "csrc" / "sc_device.h", ROOT / "include" / "sandcrate_hip.h"]
+DEPS = sorted((PKG / "csrc").glob("*")) + [ROOT / "include" / "sandcrate_hip.h"]
 LIB = PKG / "libsandcrate_hip.so"
 
 # -ffp-contract=off: float64 decisions must match NumPy's separately rounded multiply/add

@@ -562,7 +562,8 @@ int sc_step_begin(sc_ctx* c) {
   }
   {
     Bracket br(c, K_REORDER);
-    hipLaunchKernelGGL(k_reorder, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->perm, c->keyX, c->keyId,
+    hipLaunchKernelGGL(k_reorder, dim3((int)std::max<int64_t>(1, (launch_bound(c) + kReorderBlock - 1) / kReorderBlock)),
+                       dim3(kReorderBlock), 0, c->stream, c->counters, c->perm, c->keyX, c->keyId,
                        c->cellS, c->cellStart, c->wslotS, c->y[0], c->vx[0], c->vy[0], c->x[1], c->y[1], c->vx[1],
                        c->vy[1], c->id[1], c->cellT, c->wslotT);
   }

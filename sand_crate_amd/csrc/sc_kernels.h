@@ -256,35 +256,86 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ coun
 // of a bucket are contiguous, so even a bucket of thousands of exact-x ties (particles stopped
 // on a wall by the continuous-collision fix) ranks from cached, coalesced reads.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
+constexpr int kBigBucket = 24;    // buckets above this size are ranked cooperatively
+constexpr int kRankChunk = 1024;  // keys streamed through LDS per step
+constexpr int kReorderBlock = 64; // one wave per workgroup: a big bucket is shared by 4x more CUs
+
+__global__ void __launch_bounds__(kReorderBlock)
     k_reorder(const int* __restrict__ counters, const int* __restrict__ perm, const double* __restrict__ keyX,
               const int* __restrict__ keyId, const int* __restrict__ cellS, const int* __restrict__ cellStart,
               const int* __restrict__ wslotS, const double* __restrict__ yS, const double* __restrict__ vxS,
               const double* __restrict__ vyS, double* __restrict__ xT, double* __restrict__ yT,
               double* __restrict__ vxT, double* __restrict__ vyT, int* __restrict__ idT, int* __restrict__ cellT,
               int* __restrict__ wslotT) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= counters[C_NT]) return;
-  int i = perm[s];
-  double xi = keyX[s];
-  int idi = keyId[s];
-  int cpacked = cellS[i];
-  int c = cpacked & kCellMask;
-  double yi = yS[i], vxi = vxS[i], vyi = vyS[i];
-  int wsi = wslotS[i];
-  int b = cellStart[c], e = cellStart[c + 1];
-  int rank = 0;
-  for (int t = b; t < e; t += 4) {  // four keys in flight per round trip
-    double k0 = keyX[t], k1 = t + 1 < e ? keyX[t + 1] : xi, k2 = t + 2 < e ? keyX[t + 2] : xi,
-           k3 = t + 3 < e ? keyX[t + 3] : xi;
-    int d0 = keyId[t], d1 = t + 1 < e ? keyId[t + 1] : idi, d2 = t + 2 < e ? keyId[t + 2] : idi,
-        d3 = t + 3 < e ? keyId[t + 3] : idi;
-    rank += (k0 < xi) || (k0 == xi && d0 < idi);
-    rank += (k1 < xi) || (k1 == xi && d1 < idi);
-    rank += (k2 < xi) || (k2 == xi && d2 < idi);
-    rank += (k3 < xi) || (k3 == xi && d3 < idi);
+  __shared__ double ckx[kRankChunk];
+  __shared__ int cki[kRankChunk];
+  __shared__ int pick;
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = s < counters[C_NT];
+  int i = 0, idi = 0, cpacked = 0, c = 0, wsi = 0, b = 0, e = 0;
+  double xi = 0, yi = 0, vxi = 0, vyi = 0;
+  if (live) {
+    i = perm[s];
+    xi = keyX[s];
+    idi = keyId[s];
+    cpacked = cellS[i];
+    c = cpacked & kCellMask;
+    yi = yS[i];
+    vxi = vxS[i];
+    vyi = vyS[i];
+    wsi = wslotS[i];
+    b = cellStart[c];
+    e = cellStart[c + 1];
   }
-  int dst = b + rank;
+  int rank = 0;
+  const bool big = live && (e - b) > kBigBucket;
+  if (live && !big) {
+    for (int t = b; t < e; t += 4) {  // four keys in flight per round trip
+      double k0 = keyX[t], k1 = t + 1 < e ? keyX[t + 1] : xi, k2 = t + 2 < e ? keyX[t + 2] : xi,
+             k3 = t + 3 < e ? keyX[t + 3] : xi;
+      int d0 = keyId[t], d1 = t + 1 < e ? keyId[t + 1] : idi, d2 = t + 2 < e ? keyId[t + 2] : idi,
+          d3 = t + 3 < e ? keyId[t + 3] : idi;
+      rank += (k0 < xi) || (k0 == xi && d0 < idi);
+      rank += (k1 < xi) || (k1 == xi && d1 < idi);
+      rank += (k2 < xi) || (k2 == xi && d2 < idi);
+      rank += (k3 < xi) || (k3 == xi && d3 < idi);
+    }
+  }
+  // Buckets of thousands (particles piled up against a wall, many with exactly equal x) would cost
+  // bucket_size global reads per thread on the few CUs that own them.  The workgroup ranks such
+  // buckets together instead: their keys stream through LDS in coalesced chunks and every thread of
+  // the bucket compares against the chunk with broadcast LDS reads.  A workgroup holds consecutive
+  // slots, so it sees at most a handful of distinct buckets, taken one at a time.
+  bool pending = big;
+  while (true) {
+    __syncthreads();
+    if (threadIdx.x == 0) pick = -1;
+    __syncthreads();
+    if (pending) pick = c;  // any pending bucket will do (benign race: all writers hold valid values)
+    __syncthreads();
+    const int cur = pick;
+    if (cur < 0) break;
+    const int cb = cellStart[cur], ce = cellStart[cur + 1];
+    const bool mine = pending && c == cur;
+    for (int base = cb; base < ce; base += kRankChunk) {
+      const int len = min(kRankChunk, ce - base);
+      __syncthreads();
+      for (int k = threadIdx.x; k < len; k += kReorderBlock) {
+        ckx[k] = keyX[base + k];
+        cki[k] = keyId[base + k];
+      }
+      __syncthreads();
+      if (mine) {
+        for (int k = 0; k < len; ++k) {
+          const double kx = ckx[k];
+          rank += (kx < xi) || (kx == xi && cki[k] < idi);
+        }
+      }
+    }
+    if (mine) pending = false;
+  }
+  if (!live) return;
+  const int dst = b + rank;
   xT[dst] = xi;
   yT[dst] = yi;
   vxT[dst] = vxi;

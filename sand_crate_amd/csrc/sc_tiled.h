@@ -63,6 +63,17 @@ struct XY {
   double x, y;
 };
 
+// XCD-aware block -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
+// b + 8 share an L2), while a tile overlaps its neighbors in the sorted order (same rows) and the
+// tiles one grid row away (next / previous rows).  Giving every XCD one contiguous run of tiles
+// keeps those overlaps inside one L2 instead of fetching them once per XCD (measured with
+// FETCH_SIZE: profiles/).  Placement is a speed matter only; nothing depends on it.
+__device__ __forceinline__ int tile_of_block() {
+  const int nb = gridDim.x, b = blockIdx.x;
+  const int q = nb >> 3, r = nb & 7, xcd = b & 7;
+  return xcd * q + min(xcd, r) + (b >> 3);
+}
+
 // Phases 3-5 of pass A for one particle.  LDS: where the tile is (compile time, see the header).
 template <int NOISE, bool ENUM, bool DENS, bool LDS>
 __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, const int total, const XY* txy,
@@ -94,17 +105,28 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       const double xhi = xi + w.d, xlo = xi - w.d;
       // one scan: `count` candidates from tile slot `first`, walking by `step`; window() says
       // 0 = stop the scan, 1 = outside the window, 2 = inside
+      // From LDS candidates are fetched one by one; from global memory (a tile too large for LDS)
+      // four at a time, so that the cold-miss latency is paid once per four.  Either way they are
+      // examined one by one, in order, with the reference's stop and window conditions.
+      constexpr int kFetch = LDS ? 1 : 4;
       auto scan = [&](int first, int count, int step, auto window) {
-        int slot = first;
-        for (int v = 0; v < count; ++v, slot += step) {
-          const XY q = load_xy(slot);
-          const int verdict = window(q.x);
-          if (verdict == 0) break;
-          if (verdict == 2) {
-            const double dx = q.x - xi, dy = q.y - yi;
-            if (dx * dx + dy * dy <= w.t_nbr) {  // norm(p_j - p_i) <= d (collision_detector.py:78-79)
-              list[C][t] = (unsigned short)slot;
-              if (++C == kMaxNbr) break;         // trim (:91-93)
+        bool done = false;
+        for (int v0 = 0; v0 < count && !done; v0 += kFetch) {
+          XY q[kFetch];
+#pragma unroll
+          for (int k = 0; k < kFetch; ++k) q[k] = load_xy(v0 + k < count ? first + (v0 + k) * step : self);
+#pragma unroll
+          for (int k = 0; k < kFetch; ++k) {
+            if (done || v0 + k >= count) continue;
+            const int verdict = window(q[k].x);
+            if (verdict == 0) {
+              done = true;
+            } else if (verdict == 2) {
+              const double dx = q[k].x - xi, dy = q[k].y - yi;
+              if (dx * dx + dy * dy <= w.t_nbr) {  // norm(p_j - p_i) <= d (collision_detector.py:78-79)
+                list[C][t] = (unsigned short)(first + (v0 + k) * step);
+                if (++C == kMaxNbr) done = true;   // trim (:91-93)
+              }
             }
           }
         }
@@ -165,14 +187,25 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
   if (DENS && live) {
     double sumw = 0, ax = 0, ay = 0;
     const int off = (NOISE == SC_NOISE_HOST) ? offById[idi] : 0;
+    constexpr int kFetch = LDS ? 1 : 4;  // global-memory tiles: four neighbors per round trip
+    XY qq[kFetch];
     for (int s = 0; s < C; ++s) {
-      XY q;
-      if (slots_fit) {
-        q = load_xy((int)list[s][t]);
-      } else {
-        const int j = -nbr[(size_t)s * cap + i] - 1;
-        q = XY{x[j], y[j]};
+      if (s % kFetch == 0) {
+#pragma unroll
+        for (int k = 0; k < kFetch; ++k) {
+          const int sk = s + k;
+          if (slots_fit) {
+            qq[k] = load_xy(sk < C ? (int)list[sk][t] : self);
+          } else {
+            const int j = sk < C ? -nbr[(size_t)sk * cap + i] - 1 : i;
+            qq[k] = XY{x[j], y[j]};
+          }
+        }
       }
+      XY q = qq[0];
+#pragma unroll
+      for (int k = 1; k < kFetch; ++k)
+        if (s % kFetch == k) q = qq[k];
       double ex, ey;
       collider_noise<NOISE>(w, idi, s, eta, off, ex, ey);
       const double rx = pi.x - (q.x + ex), ry = pi.y - (q.y + ey);  // crate.py:167-171
@@ -223,7 +256,8 @@ __global__ void __launch_bounds__(kTileW)
   __shared__ int bounds[6];
 
   const int t = threadIdx.x;
-  const int i0 = blockIdx.x * kTileW;
+  const int tile_id = tile_of_block();
+  const int i0 = tile_id * kTileW;
   const int i = i0 + t;
   // everything that does not depend on the live count is requested before the count is waited for
   const int ic = min(i, cap - 1);
@@ -285,7 +319,7 @@ __global__ void __launch_bounds__(kTileW)
     }
   }
   __syncthreads();
-  if (ENUM && t < 6) tileBounds[6 * blockIdx.x + t] = bounds[t];  // pass B stages the same three ranges
+  if (ENUM && t < 6) tileBounds[6 * tile_id + t] = bounds[t];  // pass B stages the same three ranges
 
   if (in_lds)
     pass_a_body<NOISE, ENUM, DENS, true>(w, tl, total, txy, list, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr, cnt,
@@ -436,12 +470,13 @@ __global__ void __launch_bounds__(kTileW)
   __shared__ Rec tile[kTileCapB];
 
   const int t = threadIdx.x;
-  const int i0 = blockIdx.x * kTileW;
+  const int tile_id = tile_of_block();
+  const int i0 = tile_id * kTileW;
   const int i = i0 + t;
   // 1. one round trip: the three ranges (published by pass A for this very block), the particle's
   // scalars and all twenty table entries -- none of these loads waits for another
   const int ic = min(i, cap - 1);
-  const int* tb = tileBounds + 6 * blockIdx.x;
+  const int* tb = tileBounds + 6 * tile_id;
   const int tb0 = tb[0], tb1 = tb[1], tb2 = tb[2], tb3 = tb[3], tb4 = tb[4], tb5 = tb[5];
   const int cpacked = cell[ic];
   const int Craw = cnt[ic];
@@ -451,7 +486,7 @@ __global__ void __launch_bounds__(kTileW)
 #pragma unroll
   for (int s = 0; s < kMaxNbr; ++s) js[s] = nbr[(size_t)s * cap + ic];
   const int n = counters[C_NT];
-  if (blockIdx.x == 0 && t == 0) {
+  if (tile_id == 0 && t == 0) {
     counters[C_NS] = n;    // the storage arrays now hold the n live particles
     counters[C_WREC] = 0;  // per-tick counters start the next tick at zero (sc_step_stats reads them
     counters[C_SUMC] = 0;  // between sc_step_begin and sc_step_finish, i.e. before this kernel)

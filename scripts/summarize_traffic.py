@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Turns the counter CSVs of scripts/collect_traffic.sh into profiles/r01_traffic_<N>.json:
+per kernel, average FETCH_SIZE / WRITE_SIZE per launch in bytes, raw and calibrated."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+out_dir, n = sys.argv[1], int(sys.argv[2])
+
+
+def per_kernel(path, counter):
+    files = glob.glob(f"{path}/*/*counter_collection.csv")
+    if not files:
+        raise SystemExit(f"no counter file under {path}")
+    tot, cnt = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(files[0])):
+        if r["Counter_Name"] != counter:
+            continue
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        tot[k] += float(r["Counter_Value"])
+        cnt[k] += 1
+    return {k: tot[k] / cnt[k] * 1024.0 for k in tot}  # counter unit: KiB
+
+
+GiB = float(1 << 30)
+cal_f = per_kernel(f"{out_dir}/calib_FETCH_SIZE", "FETCH_SIZE")["copy_f64"]
+cal_w = per_kernel(f"{out_dir}/calib_WRITE_SIZE", "WRITE_SIZE")["copy_f64"]
+kf, kw = GiB / cal_f, GiB / cal_w  # true bytes per counted byte, 8 B per lane coalesced
+fetch = per_kernel(f"{out_dir}/bench_FETCH_SIZE", "FETCH_SIZE")
+write = per_kernel(f"{out_dir}/bench_WRITE_SIZE", "WRITE_SIZE")
+names = {"sc::k_wall_bin": "wall_bin", "sc::k_scan_local": "cell_scan(local)", "sc::k_scan_fix": "cell_scan(fix)",
+         "sc::k_scatter": "scatter", "sc::k_reorder": "reorder"}
+res = {"particles": n, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, --kernel-trace only; unit KiB",
+       "calibration": {"kernel": "float64 copy, 8 B per lane, 1 GiB read + 1 GiB written (scripts/traffic_calib.hip)",
+                       "fetch_counted_bytes": cal_f, "write_counted_bytes": cal_w,
+                       "fetch_factor": kf, "write_factor": kw},
+       "note": "the counters sit on the L2's memory side: Infinity Cache hits are included, so at this size "
+               "(working set < 256 MiB) this is L2<->fabric traffic, an upper bound of HBM traffic",
+       "kernels": {}}
+for k in sorted(set(fetch) | set(write)):
+    if not k.startswith("sc::"):
+        continue
+    name = names.get(k, "neighbors_density" if "k_pass_a" in k else "force_integrate" if "k_pass_b" in k else k)
+    f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+    res["kernels"][name] = {"fetch_bytes_raw": f, "write_bytes_raw": w, "fetch_bytes": f * kf, "write_bytes": w * kw,
+                            "traffic_bytes": f * kf + w * kw, "traffic_bytes_per_particle": (f * kf + w * kw) / n}
+path = f"profiles/r01_traffic_{n}.json"
+json.dump(res, open(path, "w"), indent=1)
+print(json.dumps(res["calibration"]))
+for k, v in res["kernels"].items():
+    print(f"{k:22s} fetch {v['fetch_bytes']/1e6:8.2f} MB  write {v['write_bytes']/1e6:8.2f} MB  = {v['traffic_bytes_per_particle']:7.1f} B/particle")
+print("wrote", path)
