@@ -273,3 +273,104 @@ def test_slabs_on_gpu_equal_single_gpu(sc, tmp_path, nproc):
     assert np.array_equal(got["particles"], gp)
     assert np.array_equal(got["velocities"], gv)
     assert np.array_equal(got["pressure"], gpr)
+
+
+# ------------------------------------------------------------------ full benchmark sizes
+def bench_like_crate(sc, n, noise="counter"):
+    import bench
+    wc, d = bench.world_for(n)
+    p, v = bench.synthetic_state(n)
+    crate = sc.Crate(wc, noise=noise, noise_seed=1, capacity=n + 1024)
+    crate.particles = p
+    crate.particle_velocities = v
+    return crate, wc, p, v, d
+
+
+def test_full_size_tick_matches_oracle(sc):
+    """BASELINE.json configs[1] (262,144 particles, bench.py's exact inputs): two ticks against the
+    vectorised oracle started from the same state."""
+    from oracle.scene import OracleCrate
+    from oracle.tick import counter_noise_key, counter_noise_u01, tick_core
+    from oracle.world import World
+    n = 262144
+    crate, wc, p, v, d = bench_like_crate(sc, n)
+    orc = OracleCrate(World(wc.rigid_bodies, [], dict(wc.coefficients)))
+    ids = np.arange(n)
+    for t in range(2):
+        crate.physics_tick()
+        for b in orc.rigid_bodies:
+            b.advance(orc.coef["dt"])
+        out = tick_core(p, v, orc.segments, orc.body_states(), orc.coef,
+                        eta_u01=counter_noise_u01(ids, counter_noise_key(1, t)))
+        gp, gv, gpr, gids = crate.engine.download()
+        assert np.array_equal(gids, ids)
+        np.testing.assert_allclose(gp, out["particles"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(gv, out["velocities"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(gpr, out["pressure"], rtol=1e-9, atol=1e-12)
+        p, v = gp, gv
+
+
+@pytest.mark.parametrize("n", [262144, 1048576])
+def test_full_size_properties(sc, n):
+    """Size-independent properties at BASELINE.json configs[1] and configs[2] sizes: the sort tap is
+    the lexsort of the fixed positions; every listed neighbor is within one diameter; untrimmed lists
+    are symmetric; counts match a brute-force count on a sample; trimming happens only at 20."""
+    import bench
+    wc, d = bench.world_for(n)
+    p, v = bench.synthetic_state(n)
+    eng = sc.Engine(n)
+    from sand_crate_amd import _native as N
+    eng.set_noise_mode(N.NOISE_NONE, 0)
+    eng.upload(p, v)
+    crate_like = sc.Crate(wc, noise="none", capacity=16)  # only to build the tick inputs
+    crate_like._engine.close()
+    crate_like._engine = eng
+    for b in crate_like.rigid_bodies:
+        b.apply_velocity(crate_like.dt)
+    crate_like._send_tick_inputs()
+    eng.step_begin()
+    rows, sorted_ids = eng.download_sort()
+    ids, counts, nbrs, fixed = eng.download_neighbors()
+    eng.step_finish()
+    assert len(rows) == n and np.array_equal(np.sort(sorted_ids), np.arange(n))
+    # (1) sort order == lexsort((x, row)) of the fixed positions, ties by id
+    fx_by_id = np.empty((n, 2))
+    fx_by_id[ids] = fixed
+    ref_rows = np.floor(fx_by_id[:, 1] / d).astype(np.int64)
+    ref_order = np.lexsort((fx_by_id[:, 0], ref_rows))
+    assert np.array_equal(sorted_ids, ref_order)
+    assert np.array_equal(rows, ref_rows[ref_order])
+    # (2) listed neighbors are within d (the reference's inclusive filter), nobody lists itself
+    valid = np.arange(20)[None, :] < counts[:, None]
+    assert (nbrs[valid] >= 0).all() and (nbrs[~valid] == -1).all()
+    src = np.repeat(ids, counts)
+    dst = nbrs[valid]
+    assert (src != dst).all()
+    delta = fx_by_id[dst] - fx_by_id[src]
+    assert (np.sqrt(delta[:, 0] ** 2 + delta[:, 1] ** 2) <= d).all()
+    assert counts.max() <= 20
+    # (3) where neither side was trimmed the relation is symmetric
+    cnt_by_id = np.empty(n, dtype=np.int64)
+    cnt_by_id[ids] = counts
+    both = (cnt_by_id[src] < 20) & (cnt_by_id[dst] < 20)
+    fwd = set(zip(src[both].tolist(), dst[both].tolist()))
+    assert all((b, a) in fwd for a, b in list(fwd)[:200000])
+    # (4) counts equal a brute-force disc count on a sample (min with 20)
+    rs = np.random.RandomState(0)
+    sample = rs.choice(n, 300, replace=False)
+    for i in sample:
+        dd = fx_by_id - fx_by_id[i]
+        near = int((np.sqrt(dd[:, 0] ** 2 + dd[:, 1] ** 2) <= d).sum()) - 1
+        assert cnt_by_id[i] == min(near, 20)
+    eng.close()
+
+
+def test_headless_driver_runs_a_variant(sc, tmp_path):
+    """the reference's CLI entry, one sweep variant, state recording."""
+    from sand_crate_amd.main import main
+    summary = main("config/stirring_cup.yaml", tmp_path, variants=1, ticks=30, record_every=10)
+    assert summary[0]["ticks"] == 30 and summary[0]["particles"] > 50
+    rec = np.load(tmp_path / "variant_00" / "state.npz")
+    assert rec["ticks"].tolist() == [10, 20, 30]
+    assert rec["particles_2"].shape == (summary[0]["particles"], 2)
+    assert (tmp_path / "variant_00" / "config.yaml").exists()
