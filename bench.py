@@ -162,18 +162,29 @@ def main() -> None:
     def run(k):
         sim.run(k)
 
+    device_flags = []
+
+    def settle(s):
+        """Synchronise; a condition the device flagged (a particle lost to NaN, a halo buffer that
+        overflowed) is reported in the JSON line instead of aborting the measurement."""
+        from sand_crate_amd._native import NativeError
+        try:
+            s.synchronize()
+        except NativeError as err:
+            device_flags.append(str(err))
+
     run(args.warmup)
-    sim.synchronize()
+    settle(sim)
     torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides, no per-kernel events
     eng = sim.engine
     barrier()
     torch.cuda.synchronize()
-    sim.synchronize()
+    settle(sim)
     t0 = time.perf_counter()
     run(args.steps)
-    sim.synchronize()
+    settle(sim)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -187,11 +198,11 @@ def main() -> None:
         sim = make_sim()  # same initial state, same ticks as the timed region
         eng = sim.engine
         run(args.warmup)
-        sim.synchronize()
+        settle(sim)
         eng.reset_timing()
         eng.enable_timing(True)
         run(args.steps)
-        sim.synchronize()
+        settle(sim)
         eng.enable_timing(False)
         timing = eng.timing()
 
@@ -248,6 +259,8 @@ def main() -> None:
                        "parallelism": "single GPU" if world == 1 else f"{world} x-slabs, halo exchange per tick"},
             "roofline": roofline, "kernels": kernels,
         }
+        if device_flags:
+            line["device_flags"] = sorted(set(device_flags))
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         print(json.dumps(line))

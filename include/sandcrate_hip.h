@@ -173,8 +173,8 @@ const char* sc_kernel_name(int index);
  * the counter-based noise are the same as on one GPU.  Not available with SC_NOISE_HOST.
  *
  * Per tick:  sc_halo_pack -> exchange the two buffers with the neighbors (RCCL send/recv on
- * the stream given to sc_set_stream, or any transport) -> sc_halo_unpack for each received buffer
- * -> sc_step.  Buffers are DEVICE memory of (capacity_records + 1) * 5 doubles, caller-owned (e.g.
+ * the stream given to sc_set_stream, or any transport) -> sc_halo_unpack of the two received buffers
+ * (either pointer may be NULL at a domain edge) -> sc_step.  Buffers are DEVICE memory of (capacity_records + 1) * 5 doubles, caller-owned (e.g.
  * torch tensors): record 0 is a header whose first field is the record count, records 1.. are
  * (x, y, vx, vy, id).  sc_halo_pack writes every stored particle within `halo` columns of the
  * left / right edge, including particles that have already moved out of the slab on that side
@@ -182,7 +182,7 @@ const char* sc_kernel_name(int index);
 int sc_set_slab(sc_ctx* ctx, int64_t col_lo, int64_t col_hi, int32_t halo, int32_t has_left, int32_t has_right);
 int sc_upload_state_ids(sc_ctx* ctx, const double* xy, const double* vxy, const int64_t* ids, int64_t n);
 int sc_halo_pack(sc_ctx* ctx, double* dev_left, double* dev_right, int64_t capacity_records);
-int sc_halo_unpack(sc_ctx* ctx, const double* dev_records, int64_t capacity_records);
+int sc_halo_unpack(sc_ctx* ctx, const double* dev_from_left, const double* dev_from_right, int64_t capacity_records);
 /* Synchronises.  Live particles stored in this context (dead ghost copies excluded); summed over
  * the ranks this is the global particle count. */
 int sc_owned_count(sc_ctx* ctx, int64_t* n);

@@ -80,7 +80,7 @@ SIGNATURES = {
     "sc_set_slab": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "sc_upload_state_ids": (C.c_int, [_P, _D, _D, _I64, C.c_int64]),
     "sc_halo_pack": (C.c_int, [_P, _P, _P, C.c_int64]),
-    "sc_halo_unpack": (C.c_int, [_P, _P, C.c_int64]),
+    "sc_halo_unpack": (C.c_int, [_P, _P, _P, C.c_int64]),
     "sc_owned_count": (C.c_int, [_P, _I64]),
 }
 

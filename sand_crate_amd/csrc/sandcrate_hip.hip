@@ -920,19 +920,17 @@ int sc_halo_pack(sc_ctx* c, double* dev_left, double* dev_right, int64_t cap_rec
   Bracket br(c, K_HALO_PACK);
   hipLaunchKernelGGL(k_halo_pack, dim3(grid_for(launch_bound(c))), dim3(kBlock), 0, c->stream, c->w, c->counters, c->x[0],
                      c->y[0], c->vx[0], c->vy[0], c->id[0], dev_left, dev_right, (int)cap_records);
-  hipLaunchKernelGGL(k_halo_header, dim3(1), dim3(1), 0, c->stream, c->counters, dev_left, dev_right, (int)cap_records);
   HIPCHK(hipGetLastError());
   return SC_OK;
 }
 
-int sc_halo_unpack(sc_ctx* c, const double* dev_records, int64_t cap_records) {
-  if (!c || !dev_records || cap_records < 1) return fail(SC_ERR_ARG, "bad halo buffer");
+int sc_halo_unpack(sc_ctx* c, const double* from_left, const double* from_right, int64_t cap_records) {
+  if (!c || (!from_left && !from_right) || cap_records < 1) return fail(SC_ERR_ARG, "bad halo buffers");
   if (!c->slab) return fail(SC_ERR_STATE, "sc_set_slab first");
   if (c->in_step) return fail(SC_ERR_STATE, "halo exchange happens between ticks");
   Bracket br(c, K_HALO_UNPACK);
-  hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(cap_records)), dim3(kBlock), 0, c->stream, dev_records, (int)cap_records,
-                     c->counters, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], (int)c->cap);
-  hipLaunchKernelGGL(k_halo_bump, dim3(1), dim3(1), 0, c->stream, dev_records, (int)cap_records, c->counters, (int)c->cap);
+  hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(2 * cap_records)), dim3(kBlock), 0, c->stream, from_left, from_right,
+                     (int)cap_records, c->counters, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], (int)c->cap);
   HIPCHK(hipGetLastError());
   return SC_OK;
 }

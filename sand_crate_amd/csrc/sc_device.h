@@ -66,7 +66,8 @@ enum Counter {
   C_SUMC_HI = 6,
   C_PACK_L = 7,  // halo records packed for the left / right neighbor this tick
   C_PACK_R = 8,
-  C_COUNT = 10
+  C_TICKET = 9,  // workgroups that have finished the current halo kernel (last one publishes / bumps)
+  C_COUNT = 12
 };
 
 enum Flag { F_OUT_OF_GRID = 1, F_NAN = 2, F_HALO_OVERFLOW = 4, F_CAPACITY = 8 };

@@ -412,72 +412,88 @@ __device__ __forceinline__ void collider_noise(const World& w, int id, int slot,
 // record count, so one fixed-size message per direction carries everything and the host never
 // needs to know the count.
 //   k_halo_pack   every stored particle within `halo` columns of a slab edge -- including those
-//                 that already left the slab on that side (migrants) -- goes to that neighbor.
-//   k_halo_header publishes the counts and re-arms the counters.
-//   k_halo_unpack appends a received buffer to the storage arrays; whether a record is owned or
+//                 that already left the slab on that side (migrants) -- goes to that neighbor; the
+//                 last workgroup to finish publishes the counts and re-arms the counters.
+//   k_halo_unpack appends the received buffers to the storage arrays; whether a record is owned or
 //                 a ghost here is decided by its column in K1, not by the sender.
+// Two launches per tick in all: each tiny launch costs ~4 us at this problem size.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
     k_halo_pack(World w, int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
                 const double* __restrict__ vx, const double* __restrict__ vy, const int* __restrict__ id,
                 double* __restrict__ left, double* __restrict__ right, int cap) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= counters[C_NS]) return;
-  double px = x[i];
-  if (!(fabs(px) < 1e300)) return;  // dead ghost copy (x = +inf)
-  long long col = (long long)floor(px / w.d);
-  bool toL = w.has_left && col < w.own_lo + w.halo;
-  bool toR = w.has_right && col >= w.own_hi - w.halo;
-  if (!toL && !toR) return;
-  double py = y[i], pvx = vx[i], pvy = vy[i], pid = (double)id[i];
-  if (toL) {
-    int k = atomicAdd(&counters[C_PACK_L], 1);
-    if (k < cap) {
-      double* r = left + (size_t)kHaloFields * (k + 1);
-      r[0] = px; r[1] = py; r[2] = pvx; r[3] = pvy; r[4] = pid;
+  if (i < counters[C_NS]) {
+    double px = x[i];
+    if (fabs(px) < 1e300) {  // not a dead ghost copy (x = +inf)
+      long long col = (long long)floor(px / w.d);
+      bool toL = w.has_left && col < w.own_lo + w.halo;
+      bool toR = w.has_right && col >= w.own_hi - w.halo;
+      if (toL || toR) {
+        double py = y[i], pvx = vx[i], pvy = vy[i], pid = (double)id[i];
+        if (toL) {
+          int k = atomicAdd(&counters[C_PACK_L], 1);
+          if (k < cap) {
+            double* r = left + (size_t)kHaloFields * (k + 1);
+            r[0] = px; r[1] = py; r[2] = pvx; r[3] = pvy; r[4] = pid;
+          }
+        }
+        if (toR) {
+          int k = atomicAdd(&counters[C_PACK_R], 1);
+          if (k < cap) {
+            double* r = right + (size_t)kHaloFields * (k + 1);
+            r[0] = px; r[1] = py; r[2] = pvx; r[3] = pvy; r[4] = pid;
+          }
+        }
+      }
     }
   }
-  if (toR) {
-    int k = atomicAdd(&counters[C_PACK_R], 1);
-    if (k < cap) {
-      double* r = right + (size_t)kHaloFields * (k + 1);
-      r[0] = px; r[1] = py; r[2] = pvx; r[3] = pvy; r[4] = pid;
+  // The last workgroup to get here publishes the two counts as record 0 of each buffer and re-arms
+  // the counters.  Device-scope atomics order the ticket against every workgroup's record counts;
+  // the records themselves are only read by later kernels / the NIC after the kernel boundary.
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&counters[C_TICKET], 1) == (int)gridDim.x - 1) {
+      int nl = atomicExch(&counters[C_PACK_L], 0), nr = atomicExch(&counters[C_PACK_R], 0);
+      if (nl > cap || nr > cap) atomicOr(&counters[C_FLAGS], F_HALO_OVERFLOW);
+      left[0] = (double)min(nl, cap);
+      right[0] = (double)min(nr, cap);
+      counters[C_TICKET] = 0;
     }
   }
 }
 
-__global__ void k_halo_header(int* __restrict__ counters, double* __restrict__ left, double* __restrict__ right, int cap) {
-  int nl = counters[C_PACK_L], nr = counters[C_PACK_R];
-  if (nl > cap || nr > cap) atomicOr(&counters[C_FLAGS], F_HALO_OVERFLOW);
-  left[0] = (double)min(nl, cap);
-  right[0] = (double)min(nr, cap);
-  counters[C_PACK_L] = 0;
-  counters[C_PACK_R] = 0;
-}
-
+// Appends the received buffers (either may be null) to the storage arrays.  Every workgroup reads
+// the old stored count first; the last one to finish adds the two record counts to it.
 __global__ void __launch_bounds__(kBlock)
-    k_halo_unpack(const double* __restrict__ buf, int cap, int* __restrict__ counters, double* __restrict__ x,
-                  double* __restrict__ y, double* __restrict__ vx, double* __restrict__ vy, int* __restrict__ id,
-                  int capS) {
-  int n = min((int)buf[0], cap);
-  int base = counters[C_NS];
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  if (base + k >= capS) {
-    atomicOr(&counters[C_FLAGS], F_CAPACITY);
-    return;
+    k_halo_unpack(const double* __restrict__ bufL, const double* __restrict__ bufR, int cap, int* __restrict__ counters,
+                  double* __restrict__ x, double* __restrict__ y, double* __restrict__ vx, double* __restrict__ vy,
+                  int* __restrict__ id, int capS) {
+  const int nl = bufL ? min((int)bufL[0], cap) : 0;
+  const int nr = bufR ? min((int)bufR[0], cap) : 0;
+  const int base = __hip_atomic_load(&counters[C_NS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nl + nr) {
+    const double* r = k < nl ? bufL + (size_t)kHaloFields * (k + 1) : bufR + (size_t)kHaloFields * (k - nl + 1);
+    if (base + k >= capS) {
+      atomicOr(&counters[C_FLAGS], F_CAPACITY);
+    } else {
+      x[base + k] = r[0];
+      y[base + k] = r[1];
+      vx[base + k] = r[2];
+      vy[base + k] = r[3];
+      id[base + k] = (int)r[4];
+    }
   }
-  const double* r = buf + (size_t)kHaloFields * (k + 1);
-  x[base + k] = r[0];
-  y[base + k] = r[1];
-  vx[base + k] = r[2];
-  vy[base + k] = r[3];
-  id[base + k] = (int)r[4];
-}
-
-__global__ void k_halo_bump(const double* __restrict__ buf, int cap, int* __restrict__ counters, int capS) {
-  int n = min((int)buf[0], cap);
-  counters[C_NS] = min(counters[C_NS] + n, capS);
+  __syncthreads();  // every thread of this workgroup has read `base`
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&counters[C_TICKET], 1) == (int)gridDim.x - 1) {
+      counters[C_NS] = min(base + nl + nr, capS);
+      counters[C_TICKET] = 0;
+    }
+  }
 }
 
 // live particles in the storage arrays: everything but the dead ghost copies (x = +inf) a slab tick

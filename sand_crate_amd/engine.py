@@ -170,8 +170,9 @@ class Engine:
     def halo_pack(self, dev_left: int, dev_right: int, capacity_records: int) -> None:
         N.check(self._lib.sc_halo_pack(self._ctx, N._P(dev_left), N._P(dev_right), int(capacity_records)))
 
-    def halo_unpack(self, dev_records: int, capacity_records: int) -> None:
-        N.check(self._lib.sc_halo_unpack(self._ctx, N._P(dev_records), int(capacity_records)))
+    def halo_unpack(self, dev_from_left: int | None, dev_from_right: int | None, capacity_records: int) -> None:
+        N.check(self._lib.sc_halo_unpack(self._ctx, N._P(dev_from_left) if dev_from_left else None,
+                                         N._P(dev_from_right) if dev_from_right else None, int(capacity_records)))
 
     def owned_count(self) -> int:
         n = C.c_int64(0)

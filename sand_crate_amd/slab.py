@@ -103,9 +103,9 @@ class HipSlabBackend:
     def pack(self) -> None:
         self.engine.halo_pack(self.send_left.data_ptr(), self.send_right.data_ptr(), self.halo_capacity)
 
-    def unpack(self, side: str) -> None:
-        buf = self.recv_left if side == "left" else self.recv_right
-        self.engine.halo_unpack(buf.data_ptr(), self.halo_capacity)
+    def unpack(self, from_left: bool, from_right: bool) -> None:
+        self.engine.halo_unpack(self.recv_left.data_ptr() if from_left else None,
+                                self.recv_right.data_ptr() if from_right else None, self.halo_capacity)
 
     def step(self) -> None:
         self.engine.step(1)
@@ -155,9 +155,9 @@ class SlabCrate:
         rows = max(1.0, 1.0 / d)
         expect_halo = HALO_COLUMNS * rows * (len(p) / max(rows * rows, 1.0))
         if halo_capacity is None:
-            halo_capacity = int(2.5 * expect_halo) + 4096
+            halo_capacity = int(3.0 * expect_halo) + 4096
         if capacity is None:
-            capacity = int(1.3 * len(p) / self.world) + 4 * halo_capacity + 1024
+            capacity = int(1.15 * len(p) / self.world) + 4 * halo_capacity + 1024
             capacity = max(capacity, n_own + 4 * halo_capacity + 1024)
         self.left = self.rank - 1 if self.rank > 0 else None
         self.right = self.rank + 1 if self.rank < self.world - 1 else None
@@ -166,6 +166,7 @@ class SlabCrate:
         self.backend.load(p[own], v[own], ids)
         self._host_staged = dist.is_initialized() and dist.get_backend(group) != "nccl"
         self._stage = {}
+        self._ops = None
 
     # ------------------------------------------------------------------ stepping
     @property
@@ -205,11 +206,12 @@ class SlabCrate:
             for _, _, r_cpu, recv in staged:
                 recv.copy_(r_cpu)
         else:
-            ops = []
-            for peer, send, recv in pairs:
-                ops.append(dist.P2POp(dist.isend, send, peer, self.group))
-                ops.append(dist.P2POp(dist.irecv, recv, peer, self.group))
-            for work in dist.batch_isend_irecv(ops):
+            if self._ops is None:  # the same buffers and peers every tick
+                self._ops = []
+                for peer, send, recv in pairs:
+                    self._ops.append(dist.P2POp(dist.isend, send, peer, self.group))
+                    self._ops.append(dist.P2POp(dist.irecv, recv, peer, self.group))
+            for work in dist.batch_isend_irecv(self._ops):
                 work.wait()  # stream-ordered for NCCL: the current stream waits, the host does not
 
     def run(self, n_ticks: int) -> None:
@@ -222,10 +224,7 @@ class SlabCrate:
             if self.world > 1:
                 be.pack()
                 self._exchange()
-                if self.left is not None:
-                    be.unpack("left")
-                if self.right is not None:
-                    be.unpack("right")
+                be.unpack(self.left is not None, self.right is not None)
             be.step()
             self.tick += 1
 

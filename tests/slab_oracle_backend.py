@@ -47,13 +47,16 @@ class OracleSlabBackend:
         self._fill(self.send_left, (col < self.lo + self.halo) if self.has_left else np.zeros(len(col), bool))
         self._fill(self.send_right, (col >= self.hi - self.halo) if self.has_right else np.zeros(len(col), bool))
 
-    def unpack(self, side):
-        buf = (self.recv_left if side == "left" else self.recv_right).numpy().reshape(-1, HALO_FIELDS)
-        n = int(buf[0, 0])
-        rec = buf[1:1 + n]
-        self.p = np.vstack((self.p, rec[:, 0:2]))
-        self.v = np.vstack((self.v, rec[:, 2:4]))
-        self.ids = np.concatenate((self.ids, rec[:, 4].astype(np.int64)))
+    def unpack(self, from_left, from_right):
+        for use, tensor in ((from_left, self.recv_left), (from_right, self.recv_right)):
+            if not use:
+                continue
+            buf = tensor.numpy().reshape(-1, HALO_FIELDS)
+            n = int(buf[0, 0])
+            rec = buf[1:1 + n]
+            self.p = np.vstack((self.p, rec[:, 0:2]))
+            self.v = np.vstack((self.v, rec[:, 2:4]))
+            self.ids = np.concatenate((self.ids, rec[:, 4].astype(np.int64)))
 
     def step(self):
         c = self.coef
