@@ -119,6 +119,9 @@ def main() -> None:
     ap.add_argument("--particles", type=int, default=262144, help="particles per GPU")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="particles in the CPU baseline tick (0 = skip)")
     ap.add_argument("--noise", default="counter", choices=["counter", "none"])
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development only: every rank uses cuda:0 and the gloo backend (halo staged through the "
+                         "host), to exercise the N > 1 code path on a one-GPU box; the numbers mean nothing")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket kernels with HIP events in the timed region (no roofline in the output)")
     args = ap.parse_args()
@@ -133,6 +136,8 @@ def main() -> None:
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     n_total = args.particles * world
 
@@ -141,7 +146,10 @@ def main() -> None:
     if world > 1:
         import torch.distributed as dist
         from sand_crate_amd.slab import SlabCrate
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         barrier = dist.barrier
     else:
         def barrier():
@@ -208,7 +216,7 @@ def main() -> None:
 
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0 and args.no_kernel_events:
