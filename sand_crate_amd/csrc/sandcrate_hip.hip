@@ -85,7 +85,7 @@ struct sc_ctx {
   double* keyX = nullptr;
   int* keyId = nullptr;
   int* tileBounds = nullptr;
-  int *cellCount = nullptr, *cellStart = nullptr, *blockSums = nullptr;
+  int *cellCount = nullptr, *cellStart = nullptr, *blockSums = nullptr, *blockOff = nullptr;
   int64_t cellAlloc = 0;
   double* wrec = nullptr;
   int* nbr = nullptr;
@@ -173,10 +173,12 @@ int ensure_cells(sc_ctx* c, int64_t ncells) {
   if (c->cellCount) (void)hipFree(c->cellCount);
   if (c->cellStart) (void)hipFree(c->cellStart);
   if (c->blockSums) (void)hipFree(c->blockSums);
+  if (c->blockOff) (void)hipFree(c->blockOff);
   int64_t n = ncells + 1 + ncells / 4;
   HIPCHK(dalloc(&c->cellCount, n));
   HIPCHK(dalloc(&c->cellStart, n + 1));
-  HIPCHK(dalloc(&c->blockSums, n / kScanPerBlock + 2));
+  HIPCHK(dalloc(&c->blockSums, n / kScanPerBlock + 4));
+  HIPCHK(dalloc(&c->blockOff, n / kScanPerBlock + 4));
   HIPCHK(hipMemsetAsync(c->cellCount, 0, n * sizeof(int), c->stream));
   c->cellAlloc = n;
   return SC_OK;
@@ -359,7 +361,7 @@ template <int NOISE, bool ENUM, bool DENS>
 void launch_pass_a(sc_ctx* c, int kernel_id) {
   Bracket br(c, kernel_id);
   hipLaunchKernelGGL((k_pass_a<NOISE, ENUM, DENS>), dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters,
-                     c->x[1], c->y[1], c->id[1], c->cellT, c->cellStart, c->nbr, c->cnt, (int)c->cap, c->eta, c->offById,
+                     c->x[1], c->y[1], c->id[1], c->cellT, Buckets{c->cellStart, c->blockOff}, c->nbr, c->cnt, (int)c->cap, c->eta, c->offById,
                      c->P, c->sx, c->sy, c->tileBounds);
 }
 
@@ -434,7 +436,7 @@ int sc_destroy(sc_ctx* c) {
     (void)hipFree(c->vy[s]);
     (void)hipFree(c->id[s]);
   }
-  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->cellCount, c->cellStart, c->blockSums, c->wrec,
+  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->wrec,
                   c->nbr, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
                   c->stage_xy, c->stage_vxy, c->owned_out};
   for (void* p : ptrs)
@@ -548,23 +550,25 @@ int sc_step_begin(sc_ctx* c) {
   {
     Bracket br(c, K_WALL_BIN);
     hipLaunchKernelGGL(k_wall_bin, dim3(grid), dim3(kBlock), 0, c->stream, w, c->counters, c->x[0], c->y[0], c->cellS,
-                       c->wslotS, c->cellCount, c->wrec);
+                       c->wslotS, c->cellCount, c->wrec, cap);
   }
   {
     Bracket br(c, K_SCAN);
-    rc = launch_scan(c, c->cellCount, c->cellStart, (int64_t)w.nrows * w.ncols, c->blockSums, c->counters + C_NT);
-    if (rc) return rc;
+    const int64_t ncells = (int64_t)w.nrows * w.ncols;
+    const int nb = (int)((ncells + 1 + kScanPerBlock - 1) / kScanPerBlock);  // covers the one-past-the-end entry
+    hipLaunchKernelGGL(k_scan_cells, dim3(nb), dim3(kBlock), 0, c->stream, c->cellCount, c->cellStart, (int)ncells,
+                       c->blockSums, c->blockOff, c->counters);
   }
   {
     Bracket br(c, K_SCATTER);
     hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->cellS, c->x[0],
-                       c->id[0], c->cellStart, c->cellCount, c->perm, c->keyX, c->keyId);
+                       c->id[0], Buckets{c->cellStart, c->blockOff}, c->cellCount, c->perm, c->keyX, c->keyId, cap);
   }
   {
     Bracket br(c, K_REORDER);
     hipLaunchKernelGGL(k_reorder, dim3((int)std::max<int64_t>(1, (launch_bound(c) + kReorderBlock - 1) / kReorderBlock)),
                        dim3(kReorderBlock), 0, c->stream, c->counters, c->perm, c->keyX, c->keyId,
-                       c->cellS, c->cellStart, c->wslotS, c->y[0], c->vx[0], c->vy[0], c->x[1], c->y[1], c->vx[1],
+                       c->cellS, Buckets{c->cellStart, c->blockOff}, c->wslotS, c->y[0], c->vx[0], c->vy[0], c->x[1], c->y[1], c->vx[1],
                        c->vy[1], c->id[1], c->cellT, c->wslotT);
   }
   // SC_NOISE_HOST (and the stand-alone search) stop after the lists: the host's rand block can only be

@@ -55,11 +55,12 @@ __global__ void k_bump(int* counters, int m, int reset) { counters[C_NS] = (rese
 // apply_wall_bounce (:245-259) need later.
 // ------------------------------------------------------------------------------------------
 // The per-particle part of K1; returns the particle's cell or -1 (removed / beyond the data).
-__device__ __forceinline__ int wall_and_cell(const World& w, int i, int* __restrict__ counters, double* __restrict__ x,
-                                             double* __restrict__ y, int* __restrict__ wslotS,
+__device__ __forceinline__ int wall_and_cell(const World& w, int i, int cap, int* __restrict__ counters,
+                                             double* __restrict__ x, double* __restrict__ y, int* __restrict__ wslotS,
                                              double* __restrict__ wrec) {
+  const int ic = min(i, cap - 1);  // the position is requested before the stored count is waited for
+  double px = x[ic], py = y[ic];
   if (i >= counters[C_NS]) return -1;
-  double px = x[i], py = y[i];
   if (px < w.lo || px > w.hi || py < w.lo || py > w.hi) return -1;  // crate.py:152 (dead ghosts carry x = +inf)
   bool ghost = false;
   if (w.slab) {
@@ -155,9 +156,9 @@ __device__ __forceinline__ int wall_and_cell(const World& w, int i, int* __restr
 __global__ void __launch_bounds__(kBlock) k_wall_bin(World w, int* __restrict__ counters, double* __restrict__ x,
                                                      double* __restrict__ y, int* __restrict__ cellS,
                                                      int* __restrict__ wslotS, int* __restrict__ cellCount,
-                                                     double* __restrict__ wrec) {
+                                                     double* __restrict__ wrec, int cap) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  int c = wall_and_cell(w, i, counters, x, y, wslotS, wrec);
+  int c = wall_and_cell(w, i, cap, counters, x, y, wslotS, wrec);
   if (i < counters[C_NS]) cellS[i] = c;
   // one atomic per run of equal cells in the wave; lanes without a cell get distinct negative keys
   LaneRun run = lane_run(c >= 0 ? (c & kCellMask) : -1 - (int)(threadIdx.x & 63));
@@ -223,6 +224,87 @@ __global__ void __launch_bounds__(kBlock) k_scan_fix(int* __restrict__ out, int 
   }
 }
 
+// Bucket starts in ONE launch.  They are kept in two levels -- the start of a cell inside its
+// 2048-cell block (cellStart) and the start of the block (blockOff) -- so that no second pass over
+// the cells is needed: every workgroup scans its block, and the last one to finish (ticket) scans
+// the block totals.  Readers add the two (struct Buckets).  Saves a ~5 us launch per tick.
+constexpr int kScanShift = 11;
+static_assert((1 << kScanShift) == kScanPerBlock, "block offset lookup assumes 2048 cells per scan block");
+
+struct Buckets {
+  const int* __restrict__ loc;
+  const int* __restrict__ off;
+  __device__ __forceinline__ int operator()(int c) const { return loc[c] + off[c >> kScanShift]; }
+};
+
+__global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ in, int* __restrict__ out, int n,
+                                                       int* __restrict__ blockSums, int* __restrict__ blockOff,
+                                                       int* __restrict__ counters) {
+  __shared__ int waveTot[kBlock / 64];
+  __shared__ int last;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  {
+    int base = blockIdx.x * kScanPerBlock + threadIdx.x * kScanPerThread;
+    int v[kScanPerThread];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) {
+      int e = base + k < n ? in[base + k] : 0;
+      v[k] = sum;
+      sum += e;
+    }
+    int incl = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) waveTot[wv] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int k = 0; k < wv; ++k) wbase += waveTot[k];
+    int excl = wbase + incl - sum;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k)
+      if (base + k <= n) out[base + k] = excl + v[k];  // index n: one-past-the-end entry
+    if (threadIdx.x == kBlock - 1) blockSums[blockIdx.x] = excl + sum;
+  }
+  // ticket: the block totals of all workgroups are visible to the last one (agent-scope release by
+  // every publisher, acquire by the last; MI355X_MICROARCH.md, inter-workgroup visibility)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    last = atomicAdd(&counters[C_TICKET], 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  const int nb = gridDim.x;
+  int carry = 0;
+  for (int b0 = 0; b0 < nb; b0 += kBlock) {
+    int k = b0 + threadIdx.x;
+    int e = k < nb ? __hip_atomic_load(&blockSums[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    int incl = e;
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) waveTot[wv] = incl;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+    for (int q = 0; q < kBlock / 64; ++q) {
+      if (q < wv) wbase += waveTot[q];
+      tot += waveTot[q];
+    }
+    if (k < nb) blockOff[k] = carry + wbase + incl - e;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) {
+    counters[C_NT] = carry;  // live particles = entries of the sorted arrays
+    counters[C_TICKET] = 0;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // K3  scatter: a slot inside the particle's cell bucket, in arrival order.  The returning
 // atomic counts the bucket back down to zero, so cellCount needs no clearing for the next tick.
@@ -231,22 +313,26 @@ __global__ void __launch_bounds__(kBlock) k_scan_fix(int* __restrict__ out, int 
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ counters, const int* __restrict__ cellS,
                                                     const double* __restrict__ xS, const int* __restrict__ idS,
-                                                    const int* __restrict__ cellStart, int* __restrict__ cellCount,
+                                                    Buckets bk, int* __restrict__ cellCount,
                                                     int* __restrict__ perm, double* __restrict__ keyX,
-                                                    int* __restrict__ keyId) {
+                                                    int* __restrict__ keyId, int cap) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  int c = i < counters[C_NS] ? cellS[i] : -1;
+  const int ic = min(i, cap - 1);  // loads that do not depend on the stored count go out first
+  int c = cellS[ic];
+  const double xi = xS[ic];
+  const int idi = idS[ic];
+  if (i >= counters[C_NS]) c = -1;
   if (c >= 0) c &= kCellMask;
   const int lane = threadIdx.x & 63;
   LaneRun run = lane_run(c >= 0 ? c : -1 - lane);
   int base = 0;
-  if (run.is_head && c >= 0) base = cellStart[c] + atomicSub(&cellCount[c], run.len) - run.len;
+  if (run.is_head && c >= 0) base = bk(c) + atomicSub(&cellCount[c], run.len) - run.len;
   base = __shfl(base, run.head, 64);
   if (c < 0) return;
   int pos = base + (lane - run.head);
   perm[pos] = i;
-  keyX[pos] = xS[i];
-  keyId[pos] = idS[i];
+  keyX[pos] = xi;
+  keyId[pos] = idi;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -262,7 +348,7 @@ constexpr int kReorderBlock = 64; // one wave per workgroup: a big bucket is sha
 
 __global__ void __launch_bounds__(kReorderBlock)
     k_reorder(const int* __restrict__ counters, const int* __restrict__ perm, const double* __restrict__ keyX,
-              const int* __restrict__ keyId, const int* __restrict__ cellS, const int* __restrict__ cellStart,
+              const int* __restrict__ keyId, const int* __restrict__ cellS, Buckets bk,
               const int* __restrict__ wslotS, const double* __restrict__ yS, const double* __restrict__ vxS,
               const double* __restrict__ vyS, double* __restrict__ xT, double* __restrict__ yT,
               double* __restrict__ vxT, double* __restrict__ vyT, int* __restrict__ idT, int* __restrict__ cellT,
@@ -284,8 +370,8 @@ __global__ void __launch_bounds__(kReorderBlock)
     vxi = vxS[i];
     vyi = vyS[i];
     wsi = wslotS[i];
-    b = cellStart[c];
-    e = cellStart[c + 1];
+    b = bk(c);
+    e = bk(c + 1);
   }
   int rank = 0;
   const bool big = live && (e - b) > kBigBucket;
@@ -315,7 +401,7 @@ __global__ void __launch_bounds__(kReorderBlock)
     __syncthreads();
     const int cur = pick;
     if (cur < 0) break;
-    const int cb = cellStart[cur], ce = cellStart[cur + 1];
+    const int cb = bk(cur), ce = bk(cur + 1);
     const bool mine = pending && c == cur;
     for (int base = cb; base < ce; base += kRankChunk) {
       const int len = min(kRankChunk, ce - base);

@@ -59,9 +59,8 @@ __device__ __forceinline__ double rsqrt_nr(double s) {
   return y;
 }
 
-struct XY {
-  double x, y;
-};
+// (x, y) as one 16-byte vector, so that a tile read is a single ds_read_b128 / global_load_dwordx4
+typedef double XY __attribute__((ext_vector_type(2)));
 
 // XCD-aware block -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
 // b + 8 share an L2), while a tile overlaps its neighbors in the sorted order (same rows) and the
@@ -97,7 +96,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
   // 3. neighbor list of particle i: four serial scans in the reference's order, entries are tile slots
   int C = 0;
   const int self = i - tl.a0;
-  XY pi{0, 0};
+  XY pi = {0.0, 0.0};
   if (live) pi = load_xy(self);
   if (ENUM) {
     if (live && slots_fit) {
@@ -247,7 +246,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
 template <int NOISE, bool ENUM, bool DENS>
 __global__ void __launch_bounds__(kTileW)
     k_pass_a(World w, const int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
-             const int* __restrict__ id, const int* __restrict__ cell, const int* __restrict__ cellStart,
+             const int* __restrict__ id, const int* __restrict__ cell, Buckets bk,
              int* __restrict__ nbr, unsigned char* __restrict__ cnt, int cap, const double* __restrict__ eta,
              const int* __restrict__ offById, double* __restrict__ P, double* __restrict__ sx,
              double* __restrict__ sy, int* __restrict__ tileBounds) {
@@ -272,12 +271,12 @@ __global__ void __launch_bounds__(kTileW)
   int e0 = 0, b0 = 0, b1 = 0, e1 = 0, bm = 0, em = 0;
   if (live) {
     const int c = cpacked & kCellMask;
-    e0 = cellStart[c + 2];
-    b0 = cellStart[c - 1];
-    b1 = cellStart[c + w.ncols - 1];
-    e1 = cellStart[c + w.ncols + 2];
-    bm = cellStart[c - w.ncols - 1];
-    em = cellStart[c - w.ncols + 2];
+    e0 = bk(c + 2);
+    b0 = bk(c - 1);
+    b1 = bk(c + w.ncols - 1);
+    e1 = bk(c + w.ncols + 2);
+    bm = bk(c - w.ncols - 1);
+    em = bk(c - w.ncols + 2);
     if (t == 0) {
       bounds[0] = b0;
       bounds[2] = b1;
