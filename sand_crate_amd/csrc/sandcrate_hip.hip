@@ -85,7 +85,11 @@ struct sc_ctx {
   double* keyX = nullptr;
   int* keyId = nullptr;
   int* tileBounds = nullptr;
-  int *cellCount = nullptr, *cellStart = nullptr, *blockSums = nullptr, *blockOff = nullptr;
+  int *cellCount = nullptr, *cellStart = nullptr, *blockSums = nullptr, *blockOff = nullptr, *sortedStamp = nullptr;
+  int* bigList = nullptr;
+  int* bigHintHost = nullptr;  // host-mapped: number of big buckets the last finished scan saw
+  int* bigHintDev = nullptr;
+  bool force_sort_big = false;
   int64_t cellAlloc = 0;
   double* wrec = nullptr;
   int* nbr = nullptr;
@@ -174,11 +178,14 @@ int ensure_cells(sc_ctx* c, int64_t ncells) {
   if (c->cellStart) (void)hipFree(c->cellStart);
   if (c->blockSums) (void)hipFree(c->blockSums);
   if (c->blockOff) (void)hipFree(c->blockOff);
+  if (c->sortedStamp) (void)hipFree(c->sortedStamp);
   int64_t n = ncells + 1 + ncells / 4;
   HIPCHK(dalloc(&c->cellCount, n));
   HIPCHK(dalloc(&c->cellStart, n + 1));
   HIPCHK(dalloc(&c->blockSums, n / kScanPerBlock + 4));
   HIPCHK(dalloc(&c->blockOff, n / kScanPerBlock + 4));
+  HIPCHK(dalloc(&c->sortedStamp, n));
+  HIPCHK(hipMemsetAsync(c->sortedStamp, 0, n * sizeof(int), c->stream));
   HIPCHK(hipMemsetAsync(c->cellCount, 0, n * sizeof(int), c->stream));
   c->cellAlloc = n;
   return SC_OK;
@@ -408,6 +415,15 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
   if (e == hipSuccess) e = dalloc(&c->keyX, n);
   if (e == hipSuccess) e = dalloc(&c->keyId, n);
   if (e == hipSuccess) e = dalloc(&c->tileBounds, 6 * (n / kTileW + 2));
+  if (e == hipSuccess) e = dalloc(&c->bigList, (size_t)kMaxBig);
+  if (e == hipSuccess)  // k_sort_big stages up to kSortCap (x, id, perm) triples: 128 KiB of dynamic LDS
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_big), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(kSortCap * (sizeof(double) + 2 * sizeof(int))));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->bigHintHost, sizeof(int), hipHostMallocMapped);
+  if (e == hipSuccess) {
+    *c->bigHintHost = 0;
+    e = hipHostGetDevicePointer((void**)&c->bigHintDev, c->bigHintHost, 0);
+  }
   if (e == hipSuccess) e = dalloc(&c->wrec, 5 * n);
   if (e == hipSuccess) e = dalloc(&c->nbr, (size_t)kMaxNbr * n);
   if (e == hipSuccess) e = dalloc(&c->cnt, n);
@@ -436,7 +452,7 @@ int sc_destroy(sc_ctx* c) {
     (void)hipFree(c->vy[s]);
     (void)hipFree(c->id[s]);
   }
-  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->wrec,
+  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->wrec,
                   c->nbr, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
                   c->stage_xy, c->stage_vxy, c->owned_out};
   for (void* p : ptrs)
@@ -446,6 +462,7 @@ int sc_destroy(sc_ctx* c) {
       (void)hipEventDestroy(e.a);
       (void)hipEventDestroy(e.b);
     }
+  if (c->bigHintHost) (void)hipHostFree(c->bigHintHost);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return SC_OK;
@@ -557,19 +574,28 @@ int sc_step_begin(sc_ctx* c) {
     const int64_t ncells = (int64_t)w.nrows * w.ncols;
     const int nb = (int)((ncells + 1 + kScanPerBlock - 1) / kScanPerBlock);  // covers the one-past-the-end entry
     hipLaunchKernelGGL(k_scan_cells, dim3(nb), dim3(kBlock), 0, c->stream, c->cellCount, c->cellStart, (int)ncells,
-                       c->blockSums, c->blockOff, c->counters);
+                       c->blockSums, c->blockOff, c->counters, c->bigList, c->bigHintDev);
   }
   {
     Bracket br(c, K_SCATTER);
     hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->cellS, c->x[0],
                        c->id[0], Buckets{c->cellStart, c->blockOff}, c->cellCount, c->perm, c->keyX, c->keyId, cap);
   }
+  const int stamp = (int)((c->tick + 1) & 0x3FFFFFFF);
+  // big buckets were seen by the last scan the host knows about (an unsynchronised, possibly stale
+  // hint in host-mapped memory): sort this tick's big buckets properly before ranking
+  if (c->force_sort_big || *(volatile int*)c->bigHintHost > 0) {
+    Bracket br(c, K_SCAN);
+    hipLaunchKernelGGL(k_sort_big, dim3(64), dim3(kSortBlock), kSortCap * (sizeof(double) + 2 * sizeof(int)), c->stream,
+                       c->counters, c->bigList, Buckets{c->cellStart, c->blockOff}, c->keyX, c->keyId, c->perm,
+                       c->sortedStamp, stamp);
+  }
   {
     Bracket br(c, K_REORDER);
     hipLaunchKernelGGL(k_reorder, dim3((int)std::max<int64_t>(1, (launch_bound(c) + kReorderBlock - 1) / kReorderBlock)),
                        dim3(kReorderBlock), 0, c->stream, c->counters, c->perm, c->keyX, c->keyId,
                        c->cellS, Buckets{c->cellStart, c->blockOff}, c->wslotS, c->y[0], c->vx[0], c->vy[0], c->x[1], c->y[1], c->vx[1],
-                       c->vy[1], c->id[1], c->cellT, c->wslotT);
+                       c->vy[1], c->id[1], c->cellT, c->wslotT, c->sortedStamp, stamp);
   }
   // SC_NOISE_HOST (and the stand-alone search) stop after the lists: the host's rand block can only be
   // indexed once every count is known.  Otherwise the search and pass A are one launch.
@@ -836,6 +862,7 @@ int sc_neighbor_search(int device, const double* xy, int64_t n, double diameter,
   int rc = sc_create(device, n, &c);
   if (rc) return rc;
   c->custom_grid = true;
+  c->force_sort_big = true;  // no previous tick to take the hint from
   c->custom_d = diameter;
   c->grid_row0 = (long long)r0 - 1;
   c->grid_col0 = (long long)c0 - 1;

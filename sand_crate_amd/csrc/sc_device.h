@@ -67,6 +67,7 @@ enum Counter {
   C_PACK_L = 7,  // halo records packed for the left / right neighbor this tick
   C_PACK_R = 8,
   C_TICKET = 9,  // workgroups that have finished the current halo kernel (last one publishes / bumps)
+  C_NBIG = 10,   // buckets above kSortThreshold listed this tick
   C_COUNT = 12
 };
 

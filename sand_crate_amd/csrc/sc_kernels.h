@@ -228,6 +228,9 @@ __global__ void __launch_bounds__(kBlock) k_scan_fix(int* __restrict__ out, int 
 // 2048-cell block (cellStart) and the start of the block (blockOff) -- so that no second pass over
 // the cells is needed: every workgroup scans its block, and the last one to finish (ticket) scans
 // the block totals.  Readers add the two (struct Buckets).  Saves a ~5 us launch per tick.
+constexpr int kSortThreshold = 96;  // buckets above this many particles are sorted by k_sort_big
+constexpr int kSortCap = 8192;      // ... up to this many (128 KiB of LDS); larger ones keep the k^2 ranking
+constexpr int kMaxBig = 4096;       // room in the list of big buckets
 constexpr int kScanShift = 11;
 static_assert((1 << kScanShift) == kScanPerBlock, "block offset lookup assumes 2048 cells per scan block");
 
@@ -239,7 +242,8 @@ struct Buckets {
 
 __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ in, int* __restrict__ out, int n,
                                                        int* __restrict__ blockSums, int* __restrict__ blockOff,
-                                                       int* __restrict__ counters) {
+                                                       int* __restrict__ counters, int* __restrict__ bigList,
+                                                       volatile int* __restrict__ bigHint) {
   __shared__ int waveTot[kBlock / 64];
   __shared__ int last;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -252,6 +256,10 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
       int e = base + k < n ? in[base + k] : 0;
       v[k] = sum;
       sum += e;
+      if (e > kSortThreshold) {  // rare: a bucket worth sorting properly
+        int q = atomicAdd(&counters[C_NBIG], 1);
+        if (q < kMaxBig) bigList[q] = base + k;
+      }
     }
     int incl = sum;
     for (int o = 1; o < 64; o <<= 1) {
@@ -302,6 +310,72 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
   if (threadIdx.x == 0) {
     counters[C_NT] = carry;  // live particles = entries of the sorted arrays
     counters[C_TICKET] = 0;
+    // a hint for the host, in host-mapped memory: were there big buckets?  It is read without any
+    // synchronisation when the NEXT tick is enqueued and only decides whether k_sort_big is launched.
+    *bigHint = __hip_atomic_load(&counters[C_NBIG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3b  sort of big buckets.  Ranking a bucket of k particles inside K4 costs k^2 compares, which is
+// what a pile of thousands of particles stopped on a wall -- all with exactly the same x -- turns
+// into hundreds of microseconds.  Buckets listed by the scan are instead sorted here by (x, id) with
+// a bitonic network in LDS, written back in order and stamped; K4 then takes rank = slot - start.
+// Fixed small grid, one workgroup per bucket at a time.  Launched only when the previous tick saw
+// big buckets; without it K4 falls back to its cooperative k^2 ranking.
+// ------------------------------------------------------------------------------------------
+constexpr int kSortBlock = 1024;  // 16 waves: the network is 91 dependent LDS stages, latency needs covering
+
+__global__ void __launch_bounds__(kSortBlock)
+    k_sort_big(const int* __restrict__ counters, const int* __restrict__ bigList, Buckets bk, double* __restrict__ keyX,
+               int* __restrict__ keyId, int* __restrict__ perm, int* __restrict__ sortedStamp, int stamp) {
+  extern __shared__ double sort_lds[];
+  double* sx = sort_lds;                               // kSortCap doubles
+  int* si = reinterpret_cast<int*>(sx + kSortCap);     // kSortCap ints
+  int* sp = si + kSortCap;                             // kSortCap ints
+  const int nbig = min(__hip_atomic_load(&counters[C_NBIG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), kMaxBig);
+  for (int q = blockIdx.x; q < nbig; q += gridDim.x) {
+    const int c = bigList[q];
+    const int b = bk(c), k = bk(c + 1) - b;
+    if (k > kSortCap || k < 2) continue;
+    int n2 = 1;
+    while (n2 < k) n2 <<= 1;
+    __syncthreads();
+    for (int t = threadIdx.x; t < n2; t += kSortBlock) {
+      const bool in = t < k;
+      sx[t] = in ? keyX[b + t] : __builtin_huge_val();
+      si[t] = in ? keyId[b + t] : 0x7FFFFFFF;
+      sp[t] = in ? perm[b + t] : 0;
+    }
+    for (int size = 2; size <= n2; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < (n2 >> 1); t += kSortBlock) {
+          const int i = 2 * t - (t & (stride - 1));
+          const int j = i + stride;
+          const bool up = (i & size) == 0;
+          const double xi = sx[i], xj = sx[j];
+          const int di = si[i], dj = si[j];
+          const bool gt = (xi > xj) || (xi == xj && di > dj);
+          if (gt == up) {
+            sx[i] = xj;
+            sx[j] = xi;
+            si[i] = dj;
+            si[j] = di;
+            const int pi = sp[i];
+            sp[i] = sp[j];
+            sp[j] = pi;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < k; t += kSortBlock) {
+      keyX[b + t] = sx[t];
+      keyId[b + t] = si[t];
+      perm[b + t] = sp[t];
+    }
+    if (threadIdx.x == 0) sortedStamp[c] = stamp;
   }
 }
 
@@ -352,7 +426,7 @@ __global__ void __launch_bounds__(kReorderBlock)
               const int* __restrict__ wslotS, const double* __restrict__ yS, const double* __restrict__ vxS,
               const double* __restrict__ vyS, double* __restrict__ xT, double* __restrict__ yT,
               double* __restrict__ vxT, double* __restrict__ vyT, int* __restrict__ idT, int* __restrict__ cellT,
-              int* __restrict__ wslotT) {
+              int* __restrict__ wslotT, const int* __restrict__ sortedStamp, int stamp) {
   __shared__ double ckx[kRankChunk];
   __shared__ int cki[kRankChunk];
   __shared__ int pick;
@@ -374,8 +448,11 @@ __global__ void __launch_bounds__(kReorderBlock)
     e = bk(c + 1);
   }
   int rank = 0;
-  const bool big = live && (e - b) > kBigBucket;
-  if (live && !big) {
+  // a bucket k_sort_big has put in (x, id) order this tick: the slot is the rank
+  const bool presorted = live && (e - b) > kSortThreshold && sortedStamp[c] == stamp;
+  if (presorted) rank = s - b;
+  const bool big = live && !presorted && (e - b) > kBigBucket;
+  if (live && !big && !presorted) {
     for (int t = b; t < e; t += 4) {  // four keys in flight per round trip
       double k0 = keyX[t], k1 = t + 1 < e ? keyX[t + 1] : xi, k2 = t + 2 < e ? keyX[t + 2] : xi,
              k3 = t + 3 < e ? keyX[t + 3] : xi;

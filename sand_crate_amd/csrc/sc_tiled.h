@@ -491,6 +491,7 @@ __global__ void __launch_bounds__(kTileW)
     counters[C_SUMC] = 0;  // between sc_step_begin and sc_step_finish, i.e. before this kernel)
     counters[C_SUMC_HI] = 0;
     counters[C_MAXC] = 0;
+    counters[C_NBIG] = 0;
   }
   if (i0 >= n) return;
   const int m = min(kTileW, n - i0);
