@@ -31,10 +31,11 @@ class BodyState:
 
 
 # Counter-based collider noise used when the stream is not the host's MT19937.
-# The HIP kernels implement the same function (sand_crate_amd/csrc/sc_device.h, sc_noise_u01).
+# The HIP kernels implement the same function (sand_crate_amd/csrc/sc_device.h: noise_base, noise_eta).
 _M1 = np.uint64(0xFF51AFD7ED558CCD)
 _M2 = np.uint64(0xC4CEB9FE1A85EC53)
 _GOLD = np.uint64(0x9E3779B97F4A7C15)
+_MIX = np.uint64(0xD6E8FEB86659FD93)
 
 
 def _mix64(z: np.ndarray) -> np.ndarray:
@@ -56,7 +57,10 @@ def counter_noise_u01(ids: np.ndarray, key: np.uint64) -> np.ndarray:
     with np.errstate(over="ignore"):
         slot = np.arange(MAX_NEIGHBORS, dtype=np.uint64)[None, :]
         ctr = ids.astype(np.uint64)[:, None] * np.uint64(32) + slot
-        h = _mix64((ctr * _GOLD) ^ key)
+        h = ctr * _GOLD + key
+        h = h ^ (h >> np.uint64(32))
+        h = h * _MIX
+        h = h ^ (h >> np.uint64(32))
     hi = (h >> np.uint64(32)).astype(np.float64)
     lo = (h & np.uint64(0xFFFFFFFF)).astype(np.float64)
     return np.stack((hi, lo), axis=-1) * (1.0 / 4294967296.0)

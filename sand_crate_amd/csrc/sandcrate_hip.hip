@@ -58,15 +58,6 @@ double sq_threshold(double R) {
   return t;
 }
 
-uint64_t host_mix64(uint64_t z) {
-  z ^= z >> 33;
-  z *= 0xFF51AFD7ED558CCDull;
-  z ^= z >> 33;
-  z *= 0xC4CEB9FE1A85EC53ull;
-  z ^= z >> 33;
-  return z;
-}
-
 template <class T>
 hipError_t dalloc(T** p, size_t n) {
   return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T));
@@ -286,6 +277,7 @@ int make_world(sc_ctx* c) {
     w.ncols = (int)(ccmax - ccmin + 1) + 2;
   }
   w.inv_d = 1.0 / w.d;
+  w.eta_scale = (w.d * w.level) * (1.0 / 4294967296.0);
   w.nseg = c->nseg;
   w.nbody = c->nbody;
   std::memcpy(w.seg, c->seg, sizeof w.seg);
@@ -293,7 +285,7 @@ int make_world(sc_ctx* c) {
   std::memcpy(w.body, c->body, sizeof w.body);
   w.noise_mode = c->noise_mode;
   w.tick = (int)c->tick;
-  w.noise_key = host_mix64(c->seed + (uint64_t)(c->tick + 1) * 0x9E3779B97F4A7C15ull);
+  w.noise_key = mix64(c->seed + (uint64_t)(c->tick + 1) * kGold);
   w.slab = c->slab ? 1 : 0;
   w.own_lo = c->slab ? c->own_lo : std::numeric_limits<long long>::min();
   w.own_hi = c->slab ? c->own_hi : std::numeric_limits<long long>::max();

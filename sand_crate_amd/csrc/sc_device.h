@@ -31,6 +31,7 @@ struct World {
   // coefficients (crate.py:42-57)
   double dt, r, d, decay, pamp, ignored, level, visc, ss, tp, gx, gy;
   double inv_d;      // 1/d, for the float-tolerance math only (never for a decision)
+  double eta_scale;  // d * collider_noise_level / 2^32, for the counter noise
   // decision thresholds derived on the host, see sc_host.cpp: make_world()
   double t_nbr;      // largest s with sqrt(s) <= d          (collision_detector.py:78-79)
   double t_wall;     // largest s with sqrt(s) <= r * 1.2    (crate.py:229)
@@ -77,9 +78,16 @@ constexpr int kGhostBit = 1 << 30;  // set in a particle's packed cell index whe
 constexpr int kCellMask = kGhostBit - 1;
 constexpr int kHaloFields = 5;      // x, y, vx, vy, id per halo record
 
-// Counter-based collider noise: two uniforms in [0,1) with 32 bits each from one 64-bit hash of
+// Counter-based collider noise: two uniforms with 32 bits each from one 64-bit hash of
 // (tick key, particle id, slot).  oracle/tick.py:counter_noise_u01 is the same function.
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+//   z = (id * 32 + slot) * GOLD + key;  z ^= z >> 32;  z *= MIX;  z ^= z >> 32;  u_x = hi32 / 2^32, u_y = lo32 / 2^32
+// The per-particle part of z is hoisted out of the pair loops (noise_base) and the slot part is a
+// running add of GOLD, so one pair costs one 64-bit multiply.  The offset (u - 0.5) * d * level is
+// formed as (hi32 - 2^31) * (d * level / 2^32): one signed convert and one multiply per component.
+constexpr uint64_t kGold = 0x9E3779B97F4A7C15ull;
+constexpr uint64_t kMix = 0xD6E8FEB86659FD93ull;
+
+__device__ __host__ __forceinline__ uint64_t mix64(uint64_t z) {  // used for the per-tick key only
   z ^= z >> 33;
   z *= 0xFF51AFD7ED558CCDull;
   z ^= z >> 33;
@@ -88,11 +96,18 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
   return z;
 }
 
-__device__ __forceinline__ void noise_u01(uint64_t key, int id, int slot, double& ux, double& uy) {
-  uint64_t ctr = (uint64_t)(uint32_t)id * 32ull + (uint64_t)slot;
-  uint64_t h = mix64((ctr * 0x9E3779B97F4A7C15ull) ^ key);
-  ux = (double)(uint32_t)(h >> 32) * (1.0 / 4294967296.0);
-  uy = (double)(uint32_t)(h & 0xFFFFFFFFull) * (1.0 / 4294967296.0);
+__device__ __forceinline__ uint64_t noise_base(uint64_t key, int id) {
+  return ((uint64_t)(uint32_t)id * 32ull) * kGold + key;
+}
+
+__device__ __forceinline__ void noise_eta(uint64_t z, double eta_scale, double& ex, double& ey) {
+  z ^= z >> 32;
+  z *= kMix;
+  z ^= z >> 32;
+  const int hi = (int)((uint32_t)(z >> 32) ^ 0x80000000u);  // hi32 - 2^31 as a signed integer
+  const int lo = (int)((uint32_t)z ^ 0x80000000u);
+  ex = (double)hi * eta_scale;
+  ey = (double)lo * eta_scale;
 }
 
 // Runs of equal keys among the lanes of a wave.  Storage order is the previous tick's sorted order,

@@ -550,22 +550,19 @@ __global__ void k_count_by_id(const int* __restrict__ counters, const int* __res
   if (i < counters[C_NT]) cntById[id[i]] = cnt[i];
 }
 
-// Collider offset eta_ij of crate.py:169 for (particle id, slot).
+// Collider offset eta_ij of crate.py:169 for slot `slot` of a particle.  `z` is the particle's
+// noise_base plus slot * GOLD (counter mode), `off` its offset into the host's block (host mode).
 template <int NOISE>
-__device__ __forceinline__ void collider_noise(const World& w, int id, int slot, const double* __restrict__ eta,
+__device__ __forceinline__ void collider_noise(const World& w, uint64_t z, int slot, const double* __restrict__ eta,
                                                int off, double& ex, double& ey) {
   if (NOISE == SC_NOISE_NONE) {
     ex = ey = 0.0;
-  } else {
-    double ux, uy;
-    if (NOISE == SC_NOISE_HOST) {
-      ux = eta[2 * ((size_t)off + slot)];
-      uy = eta[2 * ((size_t)off + slot) + 1];
-    } else {
-      noise_u01(w.noise_key, id, slot, ux, uy);
-    }
-    ex = (ux - 0.5) * w.d * w.level;
+  } else if (NOISE == SC_NOISE_HOST) {
+    const double ux = eta[2 * ((size_t)off + slot)], uy = eta[2 * ((size_t)off + slot) + 1];
+    ex = (ux - 0.5) * w.d * w.level;  // crate.py:169, operation for operation
     ey = (uy - 0.5) * w.d * w.level;
+  } else {
+    noise_eta(z, w.eta_scale, ex, ey);
   }
 }
 

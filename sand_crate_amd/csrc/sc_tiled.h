@@ -49,14 +49,14 @@ __device__ __host__ __forceinline__ int tile_index(const Tile& t, int slot) {  /
 // A neighbor-table entry is a tile slot (>= 0) or, for a tile too large for u16 slots, -(index+1).
 __device__ __host__ __forceinline__ int entry_index(const Tile& t, int e) { return e >= 0 ? tile_index(t, e) : -e - 1; }
 
-// 1/sqrt(s) to about 1 ulp: hardware estimate + two Newton steps (explicit fma; nothing here
-// feeds a decision).  s = 0 gives NaN downstream, like the reference's 0/0 (crate.py:174).
+// 1/sqrt(s) to about 2 ulp (explicit fma; nothing here feeds a decision).  s = 0 gives NaN downstream, like the reference's 0/0 (crate.py:174).
 __device__ __forceinline__ double rsqrt_nr(double s) {
-  double y = __builtin_amdgcn_rsq(s);
-  const double h = 0.5 * s;
-  y = y * fma(-h * y, y, 1.5);
-  y = y * fma(-h * y, y, 1.5);
-  return y;
+  // v_rsq_f64 is good to ~2^-24 (measured 5e-8); one third-order step, y (1 + e/2 + 3e^2/8) with
+  // e = 1 - s y^2, brings it to ~2e-16 in five fp64 operations
+  const double y = __builtin_amdgcn_rsq(s);
+  const double e = fma(-(s * y), y, 1.0);
+  const double p = fma(e, 0.375, 0.5);
+  return fma(y * e, p, y);
 }
 
 // (x, y) as one 16-byte vector, so that a tile read is a single ds_read_b128 / global_load_dwordx4
@@ -186,6 +186,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
   if (DENS && live) {
     double sumw = 0, ax = 0, ay = 0;
     const int off = (NOISE == SC_NOISE_HOST) ? offById[idi] : 0;
+    uint64_t z = noise_base(w.noise_key, idi);
     constexpr int kFetch = LDS ? 1 : 4;  // global-memory tiles: four neighbors per round trip
     XY qq[kFetch];
     for (int s = 0; s < C; ++s) {
@@ -206,7 +207,8 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       for (int k = 1; k < kFetch; ++k)
         if (s % kFetch == k) q = qq[k];
       double ex, ey;
-      collider_noise<NOISE>(w, idi, s, eta, off, ex, ey);
+      collider_noise<NOISE>(w, z, s, eta, off, ex, ey);
+      z += kGold;
       const double rx = pi.x - (q.x + ex), ry = pi.y - (q.y + ey);  // crate.py:167-171
       const double s2 = rx * rx + ry * ry;
       const double rinv = rsqrt_nr(s2);
@@ -366,13 +368,14 @@ __device__ __forceinline__ void pass_b_body(const World& w, const Tile& tl, cons
   const double xi = me.x, yi = me.y, Pi = me.P, sxi = me.sx, syi = me.sy;
   double vxi = me.vx, vyi = me.vy;
   const int off = (NOISE == SC_NOISE_HOST) ? offById[idi] : 0;
+  const uint64_t zbase = noise_base(w.noise_key, idi);
   double tx = 0, ty = 0, qx = 0, qy = 0, ux = 0, uy = 0;
 #pragma unroll
   for (int s = 0; s < kMaxNbr; ++s) {
     if (s < Cn) {
       const Rec o = load_rec(js[s]);
       double ex, ey;
-      collider_noise<NOISE>(w, idi, s, eta, off, ex, ey);
+      collider_noise<NOISE>(w, zbase + (uint64_t)s * kGold, s, eta, off, ex, ey);
       const double rx = xi - (o.x + ex), ry = yi - (o.y + ey);
       const double rinv = rsqrt_nr(rx * rx + ry * ry);
       const double nx = rx * rinv, ny = ry * rinv;
