@@ -3,6 +3,7 @@
 // per-tick kernel argument block and enqueues the kernels of sc_kernels.h on one HIP stream.
 // gfx950 (MI355X) only; there is no CPU path in this library.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <cmath>
@@ -78,7 +79,9 @@ struct sc_ctx {
   int* tileBounds = nullptr;
   int *cellCount = nullptr, *cellStart = nullptr, *blockSums = nullptr, *blockOff = nullptr, *sortedStamp = nullptr;
   int* bigList = nullptr;
-  int* bigHintHost = nullptr;  // host-mapped: number of big buckets the last finished scan saw
+  // host-mapped progress block written by the GPU, read by the host without synchronisation:
+  // [0] big buckets seen by the last finished scan, [1] ticks finished
+  int* bigHintHost = nullptr;
   int* bigHintDev = nullptr;
   bool force_sort_big = false;
   int64_t cellAlloc = 0;
@@ -369,7 +372,8 @@ void launch_pass_b(sc_ctx* c) {
   Bracket br(c, K_FORCE);
   hipLaunchKernelGGL(k_pass_b<NOISE>, dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters, c->x[1], c->y[1],
                      c->vx[1], c->vy[1], c->id[1], c->wslotT, c->cellT, c->nbr, c->cnt, (int)c->cap, c->eta,
-                     c->offById, c->P, c->sx, c->sy, c->wrec, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], c->tileBounds);
+                     c->offById, c->P, c->sx, c->sy, c->wrec, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], c->tileBounds,
+                     c->bigHintDev);
 }
 
 }  // namespace
@@ -411,9 +415,9 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
   if (e == hipSuccess)  // k_sort_big stages up to kSortCap (x, id, perm) triples: 128 KiB of dynamic LDS
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_big), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(kSortCap * (sizeof(double) + 2 * sizeof(int))));
-  if (e == hipSuccess) e = hipHostMalloc((void**)&c->bigHintHost, sizeof(int), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->bigHintHost, 2 * sizeof(int), hipHostMallocMapped);
   if (e == hipSuccess) {
-    *c->bigHintHost = 0;
+    c->bigHintHost[0] = c->bigHintHost[1] = 0;
     e = hipHostGetDevicePointer((void**)&c->bigHintDev, c->bigHintHost, 0);
   }
   if (e == hipSuccess) e = dalloc(&c->wrec, 5 * n);
@@ -551,6 +555,20 @@ int sc_step_begin(sc_ctx* c) {
   if (c->in_step) return fail(SC_ERR_STATE, "sc_step_begin called twice");
   if (c->slab && c->noise_mode == SC_NOISE_HOST) return fail(SC_ERR_STATE, "SC_NOISE_HOST is not available in slab mode");
   HIPCHK(hipSetDevice(c->device));
+  // Keep at most kMaxTicksQueued ticks of launches in flight.  The GPU publishes the number of
+  // finished ticks in host-mapped memory (pass B); nothing else is needed to know how far ahead the
+  // host is, and a bounded queue keeps per-tick hints (big buckets) at most that many ticks stale.
+  constexpr int64_t kMaxTicksQueued = 4;
+  if (!c->custom_grid) {
+    int spins = 0;
+    while (c->tick - (int64_t) * (volatile int*)(c->bigHintHost + 1) > kMaxTicksQueued) {
+      if (++spins > 64) {
+        if (hipStreamQuery(c->stream) == hipSuccess) break;  // nothing queued: the counter is simply behind (re-upload)
+        spins = 0;
+      }
+      sched_yield();
+    }
+  }
   int rc = make_world(c);
   if (rc) return rc;
   const World& w = c->w;

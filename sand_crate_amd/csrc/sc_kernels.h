@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
     counters[C_TICKET] = 0;
     // a hint for the host, in host-mapped memory: were there big buckets?  It is read without any
     // synchronisation when the NEXT tick is enqueued and only decides whether k_sort_big is launched.
-    *bigHint = __hip_atomic_load(&counters[C_NBIG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bigHint[0] = __hip_atomic_load(&counters[C_NBIG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

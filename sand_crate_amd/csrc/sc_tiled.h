@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(kTileW)
              const int* __restrict__ offById, const double* __restrict__ P, const double* __restrict__ sx,
              const double* __restrict__ sy, const double* __restrict__ wrec, double* __restrict__ xo,
              double* __restrict__ yo, double* __restrict__ vxo, double* __restrict__ vyo, int* __restrict__ ido,
-             const int* __restrict__ tileBounds) {
+             const int* __restrict__ tileBounds, volatile int* __restrict__ progress) {
   __shared__ Rec tile[kTileCapB];
 
   const int t = threadIdx.x;
@@ -495,6 +495,7 @@ __global__ void __launch_bounds__(kTileW)
     counters[C_SUMC_HI] = 0;
     counters[C_MAXC] = 0;
     counters[C_NBIG] = 0;
+    progress[1] = w.tick + 1;  // host-mapped: the host keeps at most a few ticks of launches queued
   }
   if (i0 >= n) return;
   const int m = min(kTileW, n - i0);
