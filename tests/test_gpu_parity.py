@@ -427,3 +427,85 @@ def test_pile_up_state_ticks_with_bucket_sort(sc):
         assert np.array_equal(sorted_ids, ref), f"tick {t}"
         eng.step_finish()
         crate._cache = None
+
+
+# ------------------------------------------------------------------ C-ABI contract: errors and edge cases
+def test_abi_error_behaviour(sc):
+    """include/sandcrate_hip.h: every entry point returns a code, the message is sc_last_error(), nothing
+    throws across the boundary; the binding turns codes into NativeError."""
+    from sand_crate_amd import _native as N
+    eng = sc.Engine(64)
+    with pytest.raises(N.NativeError, match="sc_set_params"):
+        eng.step_begin()                                   # inputs missing
+    wc = wave_world(sc, 0.02, 0.0)
+    co = {k: wc.coefficients[k] for k in ("dt", "particle_radius", "wall_collision_decay", "pressure_amplifier",
+                                          "ignored_pressure", "collider_noise_level", "viscosity", "surface_smoothing",
+                                          "target_pressure", "gravity")}
+    eng.set_params(**co)
+    with pytest.raises(N.NativeError, match="sc_step_begin first"):
+        eng.step_finish()                                  # call order
+    with pytest.raises(N.NativeError) as e:
+        eng.upload(np.zeros((65, 2)), np.zeros((65, 2)))   # beyond the context capacity
+    assert e.value.code == -3
+    seg = np.zeros((17, 2, 2))
+    with pytest.raises(N.NativeError) as e:
+        eng.set_segments(seg, np.zeros((34, 2, 2)), [((0, 0), (0, 0), 0.0, 17)])
+    assert e.value.code == -3                              # SC_MAX_SEGMENTS
+    eng.set_noise_mode(N.NOISE_HOST, 0)
+    eng.upload(np.array([[0.5, 0.5], [0.505, 0.5]]), np.zeros((2, 2)))
+    eng.set_segments(np.zeros((0, 2, 2)), np.zeros((0, 2, 2)), [])
+    eng.step_begin()
+    with pytest.raises(N.NativeError, match="twice"):
+        eng.step_begin()
+    with pytest.raises(N.NativeError, match="sc_set_noise_host"):
+        eng.step_finish()                                  # host noise not supplied
+    st = eng.step_stats()
+    assert (st.particles, st.neighbor_slots, st.max_neighbors) == (2, 2, 1)
+    eng.set_noise_host(np.full((2, 2), 0.5))
+    eng.step_finish()
+    with pytest.raises(N.NativeError, match="SC_NOISE_HOST"):
+        eng.step(1)
+    p, v, pr, ids = eng.download()
+    assert len(p) == 2 and ids.tolist() == [0, 1]
+    eng.close()
+
+
+def test_nan_particle_is_dropped_and_reported(sc):
+    """crate.py:206 divides by the distance to the wall; a particle exactly ON a wall becomes NaN in
+    the reference and lives on as NaN.  Here it is dropped and the next synchronising call says so."""
+    from sand_crate_amd import _native as N
+    wc = wave_world(sc, 0.02, 0.0)
+    crate = sc.Crate(wc, noise="none")
+    crate.particles = np.array([[0.0, 0.5], [0.5, 0.5], [0.6, 0.6]])   # the first one sits on the left wall
+    crate.particle_velocities = np.zeros((3, 2))
+    crate.physics_tick()
+    with pytest.raises(N.NativeError) as e:
+        crate.synchronize()
+    assert e.value.code == N.ERR_DOMAIN and "NaN" in str(e.value)
+    assert crate.particle_count == 2
+
+
+def test_live_coefficient_edits_take_effect(sc):
+    """playback.py:150-153, :221-226: gravity and coefficients are edited between ticks."""
+    wc = wave_world(sc, 0.01, 0.0)
+    crate = sc.Crate(wc, noise="none")
+    crate.particles = np.array([[0.5, 0.5]])
+    crate.particle_velocities = np.zeros((1, 2))
+    crate.physics_tick()
+    v1 = crate.particle_velocities[0].copy()
+    np.testing.assert_allclose(v1, crate.dt * crate.gravity, rtol=1e-14)
+    crate.gravity = np.array([3.0, -1.0])
+    setattr(crate, "dt", 0.001)
+    crate.physics_tick()
+    np.testing.assert_allclose(crate.particle_velocities[0], v1 + 0.001 * np.array([3.0, -1.0]), rtol=1e-14)
+
+
+def test_crate_grows_beyond_its_initial_capacity(sc):
+    wc = wave_world(sc, 0.01, 0.0)
+    crate = sc.Crate(wc, noise="none", capacity=16)
+    rs = np.random.RandomState(2)
+    pts = rs.rand(500, 2) * 0.8 + 0.1
+    crate.particles = pts
+    crate.particle_velocities = np.zeros_like(pts)
+    crate.physics_tick()
+    assert crate.particle_count == 500
