@@ -127,6 +127,17 @@ int sc_set_noise_mode(sc_ctx* ctx, int mode, uint64_t seed);
  *   sc_set_noise_host: those uniforms, (n_pairs x 2) in particle-index order, slot-minor (:169)
  *   sc_step_finish : populate_colliders ... apply_particles_velocity (:103-125)
  * sc_step(ctx, k) = k x (begin, finish) with no synchronisation; not valid in SC_NOISE_HOST mode. */
+/* Look-ahead for back-to-back ticks (optional; between sc_step_begin and sc_step_finish).  Declares the
+ * coefficients and walls of the tick AFTER the one being finished.  sc_step_finish then also performs
+ * that next tick's remove_particles / calc_virtual_colliders / apply_hard_wall_fix and the bucket counts
+ * (crate.py:93, :97-99) in the epilogue of the force kernel, while the new position is still in
+ * registers, and the next sc_step_begin skips them: one launch and one pass over the positions less per
+ * tick.  The promise is binding: the next tick must be started with exactly these inputs and without
+ * appending particles in between, otherwise sc_step_begin / sc_append_particles return SC_ERR_STATE.
+ * (Crate.physics_tick() never promises -- the viewer may edit coefficients between ticks; Crate.run()
+ * and sc_step(ctx, k > 1) do.)  Not used with slabs. */
+int sc_set_next_inputs(sc_ctx* ctx, const sc_params* p, const double* segments, int32_t n_segments,
+                       const sc_body* bodies, int32_t n_bodies);
 int sc_step_begin(sc_ctx* ctx);
 int sc_step_stats(sc_ctx* ctx, sc_stats* out);
 int sc_set_noise_host(sc_ctx* ctx, const double* u01, int64_t n_pairs);

@@ -62,6 +62,7 @@ SIGNATURES = {
     "sc_set_params": (C.c_int, [_P, C.POINTER(Params)]),
     "sc_set_segments": (C.c_int, [_P, _D, _D, C.c_int32, C.POINTER(Body), C.c_int32]),
     "sc_set_noise_mode": (C.c_int, [_P, C.c_int, C.c_uint64]),
+    "sc_set_next_inputs": (C.c_int, [_P, C.POINTER(Params), _D, C.c_int32, C.POINTER(Body), C.c_int32]),
     "sc_step_begin": (C.c_int, [_P]),
     "sc_step_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "sc_set_noise_host": (C.c_int, [_P, _D, C.c_int64]),

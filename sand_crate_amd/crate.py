@@ -184,11 +184,25 @@ class Crate:
             raise RuntimeError("Crate.run needs noise='counter' or 'none'")
         if any(src.active_ticks > self.tick for src in self.particle_sources):
             raise RuntimeError("Crate.run cannot interleave particle sources; use physics_tick()")
-        for _ in range(n_ticks):
-            for body in self.rigid_bodies:
-                body.apply_velocity(self.dt)
+        eng = self._engine
+        for k in range(n_ticks):
+            if k == 0:
+                for body in self.rigid_bodies:
+                    body.apply_velocity(self.dt)
             self._send_tick_inputs()
-            self._engine.step(1)
+            eng.step_begin()
+            if k + 1 < n_ticks:
+                # nobody can edit coefficients inside run(): promise the next tick's inputs, so that its
+                # removal / wall pass rides on this tick's force kernel (sc_set_next_inputs)
+                for body in self.rigid_bodies:
+                    body.apply_velocity(self.dt)
+                coef = {name: getattr(self, name) for name in _TICK_COEFFICIENTS}
+                bodies = self.rigid_bodies
+                seg = self.segments if bodies else np.zeros((0, 2, 2))
+                eng.set_next_inputs(gravity=self.gravity, segments=seg,
+                                    bodies=[(b.position, b.center_velocity, b.angular_clockwise_velocity, len(b))
+                                            for b in bodies], **coef)
+            eng.step_finish()
             self.tick += 1
         self._cache = None
         self._count_known = False

@@ -85,7 +85,7 @@ struct sc_ctx {
   int* bigHintDev = nullptr;
   bool force_sort_big = false;
   int64_t cellAlloc = 0;
-  double* wrec = nullptr;
+  double* wrec[2] = {nullptr, nullptr};  // wall records of even / odd ticks
   int* nbr = nullptr;
   unsigned char* cnt = nullptr;
   double *P = nullptr, *sx = nullptr, *sy = nullptr;
@@ -122,6 +122,14 @@ struct sc_ctx {
   int* stage_ids = nullptr;
   int* owned_out = nullptr;
   World w{};
+  // sc_set_next_inputs: the promised inputs of the tick after the current one
+  bool have_next = false;
+  sc_params next_params{};
+  int next_nseg = 0, next_nbody = 0;
+  Seg next_seg[kMaxSeg]{};
+  BodyK next_body[kMaxBody]{};
+  bool prebinned = false;     // the last sc_step_finish already ran K1 of the coming tick ...
+  WallInputs promised{};      // ... with these inputs
 
   bool timing = false;
   struct Ev {
@@ -224,8 +232,8 @@ int launch_scan(sc_ctx* c, const int* in, int* out, int64_t n, int* blockSums, i
 // Kernel-argument block of this tick.  The cell grid covers [-r, 1+r]^2 -- where
 // remove_particles (crate.py:152) leaves particles -- plus three cells of margin for the hard wall
 // fix, plus a ring of always-empty cells so that c-1 / c+1 / c+-ncols never leave the arrays.
-int make_world(sc_ctx* c) {
-  World& w = c->w;
+int build_world(sc_ctx* c, World& w, const sc_params& p, int nseg, const Seg* seg, const Seg* pad, int nbody,
+                const BodyK* body, int64_t tick) {
   std::memset(&w, 0, sizeof w);
   const double inf = std::numeric_limits<double>::infinity();
   if (c->custom_grid) {
@@ -242,8 +250,6 @@ int make_world(sc_ctx* c) {
     w.far_box = w.touch_box = -1.0;
     w.ccd_skip2 = inf;
   } else {
-    if (!c->have_params) return fail(SC_ERR_STATE, "sc_set_params has not been called");
-    const sc_params& p = c->params;
     if (!(p.particle_radius > 0) || !std::isfinite(p.particle_radius))
       return fail(SC_ERR_ARG, "particle_radius must be positive and finite");
     w.dt = p.dt;
@@ -281,22 +287,43 @@ int make_world(sc_ctx* c) {
   }
   w.inv_d = 1.0 / w.d;
   w.eta_scale = (w.d * w.level) * (1.0 / 4294967296.0);
-  w.nseg = c->nseg;
-  w.nbody = c->nbody;
-  std::memcpy(w.seg, c->seg, sizeof w.seg);
-  std::memcpy(w.pad, c->pad, sizeof w.pad);
-  std::memcpy(w.body, c->body, sizeof w.body);
+  w.nseg = nseg;
+  w.nbody = nbody;
+  std::memcpy(w.seg, seg, sizeof w.seg);
+  if (pad) std::memcpy(w.pad, pad, sizeof w.pad);
+  std::memcpy(w.body, body, sizeof w.body);
   w.noise_mode = c->noise_mode;
-  w.tick = (int)c->tick;
-  w.noise_key = mix64(c->seed + (uint64_t)(c->tick + 1) * kGold);
+  w.tick = (int)tick;
+  w.noise_key = mix64(c->seed + (uint64_t)(tick + 1) * kGold);
   w.slab = c->slab ? 1 : 0;
   w.own_lo = c->slab ? c->own_lo : std::numeric_limits<long long>::min();
   w.own_hi = c->slab ? c->own_hi : std::numeric_limits<long long>::max();
   w.halo = c->halo;
   w.has_left = c->has_left;
   w.has_right = c->has_right;
-  return ensure_cells(c, (int64_t)w.nrows * w.ncols);
+  return SC_OK;
 }
+
+int make_world(sc_ctx* c) {
+  if (!c->custom_grid && !c->have_params) return fail(SC_ERR_STATE, "sc_set_params has not been called");
+  int rc = build_world(c, c->w, c->params, c->nseg, c->seg, c->pad, c->nbody, c->body, c->tick);
+  if (rc) return rc;
+  return ensure_cells(c, (int64_t)c->w.nrows * c->w.ncols);
+}
+
+// the part of a tick's inputs that K1 reads (see WallInputs)
+WallInputs wall_inputs_of(const World& w) {
+  WallInputs k;
+  std::memset(&k, 0, sizeof k);
+  k.r = w.r; k.d = w.d; k.lo = w.lo; k.hi = w.hi; k.t_wall = w.t_wall; k.touch_box = w.touch_box; k.far_box = w.far_box;
+  k.row0 = w.row0; k.col0 = w.col0; k.own_lo = w.own_lo; k.own_hi = w.own_hi;
+  k.nrows = w.nrows; k.ncols = w.ncols; k.nseg = w.nseg; k.nbody = w.nbody; k.slab = w.slab;
+  std::memcpy(k.seg, w.seg, sizeof k.seg);
+  std::memcpy(k.body, w.body, sizeof k.body);
+  return k;
+}
+
+int wrec_counter_of(int64_t tick) { return (tick & 1) ? C_WREC2 : C_WREC; }
 
 int read_counters(sc_ctx* c, int* out) {
   HIPCHK(hipMemcpyAsync(out, c->counters, C_COUNT * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -316,6 +343,12 @@ int check_flags(int flags) {
 int put_particles(sc_ctx* c, const double* xy, const double* vxy, int64_t n, bool reset, const int64_t* ids = nullptr) {
   if (n < 0 || (n > 0 && (!xy || !vxy))) return fail(SC_ERR_ARG, "bad particle arrays");
   if (c->in_step) return fail(SC_ERR_STATE, "particles cannot change between sc_step_begin and sc_step_finish");
+  if (c->prebinned && !reset)
+    return fail(SC_ERR_STATE, "particles cannot be appended after sc_set_next_inputs promised the next tick");
+  if (c->prebinned && reset) {  // the promised tick is abandoned: forget its bucket counts
+    HIPCHK(hipMemsetAsync(c->cellCount, 0, c->cellAlloc * sizeof(int), c->stream));
+    c->prebinned = false;
+  }
   int64_t base = reset ? 0 : c->upper;
   if (base + n > c->cap)
     return fail(SC_ERR_CAPACITY, "%lld particles exceed the context capacity %lld", (long long)(base + n), (long long)c->cap);
@@ -367,13 +400,23 @@ void launch_pass_a(sc_ctx* c, int kernel_id) {
                      c->P, c->sx, c->sy, c->tileBounds);
 }
 
-template <int NOISE>
-void launch_pass_b(sc_ctx* c) {
+template <int NOISE, bool FUSED>
+void launch_pass_b(sc_ctx* c, const WallInputs& wn) {
   Bracket br(c, K_FORCE);
-  hipLaunchKernelGGL(k_pass_b<NOISE>, dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters, c->x[1], c->y[1],
-                     c->vx[1], c->vy[1], c->id[1], c->wslotT, c->cellT, c->nbr, c->cnt, (int)c->cap, c->eta,
-                     c->offById, c->P, c->sx, c->sy, c->wrec, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], c->tileBounds,
-                     c->bigHintDev);
+  const int cur = (int)(c->tick & 1), nxt = cur ^ 1;
+  hipLaunchKernelGGL((k_pass_b<NOISE, FUSED>), dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters, c->x[1],
+                     c->y[1], c->vx[1], c->vy[1], c->id[1], c->wslotT, c->cellT, c->nbr, c->cnt, (int)c->cap, c->eta,
+                     c->offById, c->P, c->sx, c->sy, c->wrec[cur], c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0],
+                     c->tileBounds, c->bigHintDev, wrec_counter_of(c->tick), wn, c->cellS, c->wslotS, c->cellCount,
+                     c->wrec[nxt], wrec_counter_of(c->tick + 1));
+}
+
+template <int NOISE>
+void launch_pass_b_any(sc_ctx* c, bool fused, const WallInputs& wn) {
+  if (fused)
+    launch_pass_b<NOISE, true>(c, wn);
+  else
+    launch_pass_b<NOISE, false>(c, wn);
 }
 
 }  // namespace
@@ -420,7 +463,8 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
     c->bigHintHost[0] = c->bigHintHost[1] = 0;
     e = hipHostGetDevicePointer((void**)&c->bigHintDev, c->bigHintHost, 0);
   }
-  if (e == hipSuccess) e = dalloc(&c->wrec, 5 * n);
+  if (e == hipSuccess) e = dalloc(&c->wrec[0], 5 * n);
+  if (e == hipSuccess) e = dalloc(&c->wrec[1], 5 * n);
   if (e == hipSuccess) e = dalloc(&c->nbr, (size_t)kMaxNbr * n);
   if (e == hipSuccess) e = dalloc(&c->cnt, n);
   if (e == hipSuccess) e = dalloc(&c->P, n);
@@ -448,7 +492,7 @@ int sc_destroy(sc_ctx* c) {
     (void)hipFree(c->vy[s]);
     (void)hipFree(c->id[s]);
   }
-  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->wrec,
+  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->wrec[0], c->wrec[1],
                   c->nbr, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
                   c->stage_xy, c->stage_vxy, c->owned_out};
   for (void* p : ptrs)
@@ -533,6 +577,9 @@ int sc_set_segments(sc_ctx* c, const double* segments, const double* padded, int
   if (nb > 0 && total != ns) return fail(SC_ERR_ARG, "bodies own %d segments, %d given", total, ns);
   c->nseg = ns;
   c->nbody = nb;
+  std::memset(c->seg, 0, sizeof c->seg);
+  std::memset(c->pad, 0, sizeof c->pad);
+  std::memset(c->body, 0, sizeof c->body);
   for (int k = 0; k < ns; ++k) c->seg[k] = Seg{segments[4 * k], segments[4 * k + 1], segments[4 * k + 2], segments[4 * k + 3]};
   for (int k = 0; k < 2 * ns; ++k) c->pad[k] = Seg{padded[4 * k], padded[4 * k + 1], padded[4 * k + 2], padded[4 * k + 3]};
   for (int b = 0; b < nb; ++b)
@@ -574,10 +621,16 @@ int sc_step_begin(sc_ctx* c) {
   const World& w = c->w;
   int grid = grid_for(launch_bound(c));
   int cap = (int)c->cap;
-  {
+  if (c->prebinned) {
+    // the previous sc_step_finish ran K1 of this tick with the promised inputs: they must be the inputs
+    const WallInputs now = wall_inputs_of(w);
+    if (std::memcmp(&now, &c->promised, sizeof now) != 0)
+      return fail(SC_ERR_STATE, "this tick's coefficients / segments differ from what sc_set_next_inputs promised");
+    c->prebinned = false;
+  } else {
     Bracket br(c, K_WALL_BIN);
     hipLaunchKernelGGL(k_wall_bin, dim3(grid), dim3(kBlock), 0, c->stream, w, c->counters, c->x[0], c->y[0], c->cellS,
-                       c->wslotS, c->cellCount, c->wrec, cap);
+                       c->wslotS, c->cellCount, c->wrec[c->tick & 1], cap, wrec_counter_of(c->tick));
   }
   {
     Bracket br(c, K_SCAN);
@@ -640,7 +693,7 @@ int sc_step_stats(sc_ctx* c, sc_stats* out) {
   out->particles = h[C_NT];
   out->neighbor_slots = (int64_t)(uint32_t)h[C_SUMC] + ((int64_t)h[C_SUMC_HI] << 32);
   out->max_neighbors = h[C_MAXC];
-  out->wall_particles = h[C_WREC];
+  out->wall_particles = h[wrec_counter_of(c->tick)];
   out->flags = h[C_FLAGS];
   out->reserved = 0;
   return SC_OK;
@@ -668,16 +721,37 @@ int sc_step_finish(sc_ctx* c) {
   if (!c->in_step) return fail(SC_ERR_STATE, "sc_step_finish needs sc_step_begin first");
   if (c->noise_mode == SC_NOISE_HOST && c->etaPairs < 0)
     return fail(SC_ERR_STATE, "SC_NOISE_HOST: sc_set_noise_host must be called every tick");
+  // look-ahead: run K1 of the next tick in pass B's epilogue (not for slabs: the halo exchange adds
+  // particles between the ticks)
+  WallInputs wn;
+  std::memset(&wn, 0, sizeof wn);
+  const bool fused = c->have_next && !c->slab && !c->custom_grid;
+  if (fused) {
+    World next;
+    int rc = build_world(c, next, c->next_params, c->next_nseg, c->next_seg, nullptr, c->next_nbody, c->next_body,
+                         c->tick + 1);
+    if (rc) return rc;
+    if (next.nrows != c->w.nrows || next.ncols != c->w.ncols) {
+      rc = ensure_cells(c, (int64_t)next.nrows * next.ncols);  // the radius changed: the grid may have grown
+      if (rc) return rc;
+    }
+    wn = wall_inputs_of(next);
+  }
+  c->have_next = false;
   switch (c->noise_mode) {
     case SC_NOISE_HOST:
       launch_pass_a<SC_NOISE_HOST, false, true>(c, K_DENSITY);
-      launch_pass_b<SC_NOISE_HOST>(c);
+      launch_pass_b_any<SC_NOISE_HOST>(c, fused, wn);
       break;
-    case SC_NOISE_COUNTER: launch_pass_b<SC_NOISE_COUNTER>(c); break;
+    case SC_NOISE_COUNTER: launch_pass_b_any<SC_NOISE_COUNTER>(c, fused, wn); break;
     default:
       if (c->custom_grid) launch_pass_a<SC_NOISE_NONE, false, true>(c, K_DENSITY);
-      launch_pass_b<SC_NOISE_NONE>(c);
+      launch_pass_b_any<SC_NOISE_NONE>(c, fused, wn);
       break;
+  }
+  if (fused) {
+    c->prebinned = true;
+    c->promised = wn;
   }
   HIPCHK(hipGetLastError());
   c->in_step = false;
@@ -693,9 +767,41 @@ int sc_step(sc_ctx* c, int32_t n_ticks) {
   for (int t = 0; t < n_ticks; ++t) {
     int rc = sc_step_begin(c);
     if (rc) return rc;
+    if (t + 1 < n_ticks) {  // the next tick of this call has the same inputs: promise them
+      c->next_params = c->params;
+      c->next_nseg = c->nseg;
+      c->next_nbody = c->nbody;
+      std::memcpy(c->next_seg, c->seg, sizeof c->next_seg);
+      std::memcpy(c->next_body, c->body, sizeof c->next_body);
+      c->have_next = true;
+    }
     rc = sc_step_finish(c);
     if (rc) return rc;
   }
+  return SC_OK;
+}
+
+int sc_set_next_inputs(sc_ctx* c, const sc_params* p, const double* segments, int32_t ns, const sc_body* bodies,
+                       int32_t nb) {
+  if (!c || !p) return fail(SC_ERR_ARG, "null argument");
+  if (!c->in_step) return fail(SC_ERR_STATE, "sc_set_next_inputs belongs between sc_step_begin and sc_step_finish");
+  if (ns < 0 || ns > kMaxSeg) return fail(SC_ERR_CAPACITY, "%d segments, at most %d", ns, kMaxSeg);
+  if (nb < 0 || nb > kMaxBody) return fail(SC_ERR_CAPACITY, "%d bodies, at most %d", nb, kMaxBody);
+  if (ns > 0 && !segments) return fail(SC_ERR_ARG, "null segment array");
+  int total = 0;
+  for (int b = 0; b < nb; ++b) total += bodies[b].n_segments;
+  if (nb > 0 && total != ns) return fail(SC_ERR_ARG, "bodies own %d segments, %d given", total, ns);
+  c->next_params = *p;
+  c->next_nseg = ns;
+  c->next_nbody = nb;
+  std::memset(c->next_seg, 0, sizeof c->next_seg);
+  std::memset(c->next_body, 0, sizeof c->next_body);
+  for (int k = 0; k < ns; ++k)
+    c->next_seg[k] = Seg{segments[4 * k], segments[4 * k + 1], segments[4 * k + 2], segments[4 * k + 3]};
+  for (int b = 0; b < nb; ++b)
+    c->next_body[b] = BodyK{bodies[b].position_x,        bodies[b].position_y, bodies[b].center_velocity_x,
+                            bodies[b].center_velocity_y, bodies[b].angular_clockwise_velocity, bodies[b].n_segments, 0};
+  c->have_next = true;
   return SC_OK;
 }
 

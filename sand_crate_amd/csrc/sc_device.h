@@ -56,12 +56,24 @@ struct World {
   BodyK body[kMaxBody];
 };
 
+// What K1 (removal, wall contacts, wall fix, cell index) reads of a tick's inputs: the subset of
+// World that the fused epilogue of pass B needs for the NEXT tick (sc_set_next_inputs).  Field names
+// match World so that one template serves both.
+struct WallInputs {
+  double r, d, lo, hi, t_wall, touch_box, far_box;
+  long long row0, col0, own_lo, own_hi;
+  int nrows, ncols, nseg, nbody, slab, pad_;
+  Seg seg[kMaxSeg];
+  BodyK body[kMaxBody];
+};
+
 // indices into the small device-side counter block
 enum Counter {
   C_NS = 0,     // particles in the storage arrays at the start of the tick
   C_NT = 1,     // live particles after removal (= entries of the sorted arrays)
   C_FLAGS = 2,  // error bits
-  C_WREC = 3,   // wall records appended this tick
+  C_WREC = 3,   // wall records appended for even ticks (odd ticks: C_WREC2); the two alternate so that
+                // pass B of tick t can read tick t's records while it writes tick t+1's (fused K1)
   C_SUMC = 4,   // sum of neighbor counts (low 32 bits)
   C_MAXC = 5,   // max neighbor count
   C_SUMC_HI = 6,
@@ -69,6 +81,7 @@ enum Counter {
   C_PACK_R = 8,
   C_TICKET = 9,  // workgroups that have finished the current halo kernel (last one publishes / bumps)
   C_NBIG = 10,   // buckets above kSortThreshold listed this tick
+  C_WREC2 = 11,
   C_COUNT = 12
 };
 

@@ -54,13 +54,13 @@ __global__ void k_bump(int* counters, int m, int reset) { counters[C_NS] = (rese
 // A wall record is (sum_k u_k, sum_k vel_k, V): all that apply_pressure (:295-307) and
 // apply_wall_bounce (:245-259) need later.
 // ------------------------------------------------------------------------------------------
-// The per-particle part of K1; returns the particle's cell or -1 (removed / beyond the data).
-__device__ __forceinline__ int wall_and_cell(const World& w, int i, int cap, int* __restrict__ counters,
-                                             double* __restrict__ x, double* __restrict__ y, int* __restrict__ wslotS,
-                                             double* __restrict__ wrec) {
-  const int ic = min(i, cap - 1);  // the position is requested before the stored count is waited for
-  double px = x[ic], py = y[ic];
-  if (i >= counters[C_NS]) return -1;
+// The per-particle part of K1 on a position held in registers: returns the particle's packed cell
+// or -1 (removed), the wall-record slot in `wslot`, and the position after the hard wall fix in
+// (px, py).  W is World or WallInputs.  `wrec_counter` is the counter of the tick's record buffer.
+template <class W>
+__device__ __forceinline__ int wall_and_cell(const W& w, double& px, double& py, int& wslot, int* __restrict__ counters,
+                                             int wrec_counter, double* __restrict__ wrec) {
+  wslot = -1;
   if (px < w.lo || px > w.hi || py < w.lo || py > w.hi) return -1;  // crate.py:152 (dead ghosts carry x = +inf)
   bool ghost = false;
   if (w.slab) {
@@ -77,7 +77,7 @@ __device__ __forceinline__ int wall_and_cell(const World& w, int i, int cap, int
     if (ox <= w.far_box && oy <= w.far_box) far = false;
     if (ox <= w.touch_box && oy <= w.touch_box) cand |= 1u << k;
   }
-  int wslot = far ? -1 : -2;
+  wslot = far ? -1 : -2;
   if (cand) {
     // pass 1: which segments touch (geometry_utils.py:26-38 with the reference's operation order)
     unsigned touch = 0;
@@ -127,9 +127,7 @@ __device__ __forceinline__ int wall_and_cell(const World& w, int i, int cap, int
       }
       px += fx;  // crate.py:211
       py += fy;
-      x[i] = px;
-      y[i] = py;
-      wslot = atomicAdd(&counters[C_WREC], 1);
+      wslot = atomicAdd(&counters[wrec_counter], 1);
       double* rec = wrec + 5 * (size_t)wslot;
       rec[0] = Ux;
       rec[1] = Uy;
@@ -148,21 +146,38 @@ __device__ __forceinline__ int wall_and_cell(const World& w, int i, int cap, int
     if (!ghost) atomicOr(&counters[C_FLAGS], F_OUT_OF_GRID);  // a ghost beyond the local grid is simply not needed
     return -1;
   }
-  wslotS[i] = wslot;
   return ((int)lr * w.ncols + (int)lc) | (ghost ? kGhostBit : 0);
 }
 
+// Bucket count of a wave's particles: one atomic per run of equal cells (lanes without a cell get
+// distinct negative keys).  Every lane of the wave must call it.
+__device__ __forceinline__ void count_cells(int c, int* __restrict__ cellCount) {
+  LaneRun run = lane_run(c >= 0 ? (c & kCellMask) : -1 - (int)(threadIdx.x & 63));
+  if (run.is_head && c >= 0) atomicAdd(&cellCount[c & kCellMask], run.len);
+}
 
 __global__ void __launch_bounds__(kBlock) k_wall_bin(World w, int* __restrict__ counters, double* __restrict__ x,
                                                      double* __restrict__ y, int* __restrict__ cellS,
                                                      int* __restrict__ wslotS, int* __restrict__ cellCount,
-                                                     double* __restrict__ wrec, int cap) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  int c = wall_and_cell(w, i, cap, counters, x, y, wslotS, wrec);
-  if (i < counters[C_NS]) cellS[i] = c;
-  // one atomic per run of equal cells in the wave; lanes without a cell get distinct negative keys
-  LaneRun run = lane_run(c >= 0 ? (c & kCellMask) : -1 - (int)(threadIdx.x & 63));
-  if (run.is_head && c >= 0) atomicAdd(&cellCount[c & kCellMask], run.len);
+                                                     double* __restrict__ wrec, int cap, int wrec_counter) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ic = min(i, cap - 1);  // the position is requested before the stored count is waited for
+  double px = x[ic], py = y[ic];
+  const double px0 = px, py0 = py;
+  int c = -1;
+  if (i < counters[C_NS]) {
+    int wslot;
+    c = wall_and_cell(w, px, py, wslot, counters, wrec_counter, wrec);
+    cellS[i] = c;
+    if (c >= 0) {
+      wslotS[i] = wslot;
+      if (px != px0 || py != py0) {  // moved by the hard wall fix
+        x[i] = px;
+        y[i] = py;
+      }
+    }
+  }
+  count_cells(c, cellCount);
 }
 
 // ------------------------------------------------------------------------------------------

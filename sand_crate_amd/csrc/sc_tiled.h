@@ -351,9 +351,8 @@ __device__ __forceinline__ void pass_b_body(const World& w, const Tile& tl, cons
                                             const double* __restrict__ vy, const double* __restrict__ eta,
                                             const int* __restrict__ offById, const double* __restrict__ P,
                                             const double* __restrict__ sx, const double* __restrict__ sy,
-                                            const double* __restrict__ wrec, double* __restrict__ xo,
-                                            double* __restrict__ yo, double* __restrict__ vxo, double* __restrict__ vyo,
-                                            int* __restrict__ ido) {
+                                            const double* __restrict__ wrec, double& xn, double& yn, double& vxn,
+                                            double& vyn) {
   auto load_rec = [&](int e) -> Rec {
     if constexpr (LDS) {
       return tile[e];
@@ -452,14 +451,17 @@ __device__ __forceinline__ void pass_b_body(const World& w, const Tile& tl, cons
     vxi *= fac;  // crate.py:200
     vyi *= fac;
   }
-  xo[i] = xi + w.dt * vxi;  // crate.py:361
-  yo[i] = yi + w.dt * vyi;
-  vxo[i] = vxi;
-  vyo[i] = vyi;
-  ido[i] = idi;
+  xn = xi + w.dt * vxi;  // crate.py:361
+  yn = yi + w.dt * vyi;
+  vxn = vxi;
+  vyn = vyi;
 }
 
-template <int NOISE>
+// FUSED: the epilogue also runs K1 of the NEXT tick (removal, wall contacts, hard wall fix, cell
+// index, bucket count -- sc_kernels.h: wall_and_cell) on the freshly integrated position, with the
+// next tick's walls `wn` (sc_set_next_inputs).  That tick then starts at the bucket scan: one launch
+// and one read+write of the positions less per tick.
+template <int NOISE, bool FUSED>
 __global__ void __launch_bounds__(kTileW)
     k_pass_b(World w, int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
              const double* __restrict__ vx, const double* __restrict__ vy, const int* __restrict__ id,
@@ -468,7 +470,9 @@ __global__ void __launch_bounds__(kTileW)
              const int* __restrict__ offById, const double* __restrict__ P, const double* __restrict__ sx,
              const double* __restrict__ sy, const double* __restrict__ wrec, double* __restrict__ xo,
              double* __restrict__ yo, double* __restrict__ vxo, double* __restrict__ vyo, int* __restrict__ ido,
-             const int* __restrict__ tileBounds, volatile int* __restrict__ progress) {
+             const int* __restrict__ tileBounds, volatile int* __restrict__ progress, int wrec_counter,
+             WallInputs wn, int* __restrict__ cellS, int* __restrict__ wslotS, int* __restrict__ cellCount,
+             double* __restrict__ wrec_next, int wrec_counter_next) {
   __shared__ Rec tile[kTileCapB];
 
   const int t = threadIdx.x;
@@ -490,7 +494,7 @@ __global__ void __launch_bounds__(kTileW)
   const int n = counters[C_NT];
   if (tile_id == 0 && t == 0) {
     counters[C_NS] = n;    // the storage arrays now hold the n live particles
-    counters[C_WREC] = 0;  // per-tick counters start the next tick at zero (sc_step_stats reads them
+    counters[wrec_counter] = 0;  // per-tick counters start the next tick at zero (sc_step_stats reads them
     counters[C_SUMC] = 0;  // between sc_step_begin and sc_step_finish, i.e. before this kernel)
     counters[C_SUMC_HI] = 0;
     counters[C_MAXC] = 0;
@@ -535,23 +539,37 @@ __global__ void __launch_bounds__(kTileW)
     }
   }
   __syncthreads();
-  if (!live) return;
 
-  if (ghost) {
-    xo[i] = __builtin_huge_val();  // +inf: next tick's removal test (crate.py:152) drops the copy
-    yo[i] = 0.0;
-    vxo[i] = 0.0;
-    vyo[i] = 0.0;
-    ido[i] = -1;
-    return;
+  // 3-4. pair math and epilogue; ghosts and lanes without a particle skip it
+  double xn = __builtin_huge_val(), yn = 0.0, vxn = 0.0, vyn = 0.0;  // a ghost's copy: +inf makes the next
+  int idn = -1;                                                        // removal test (crate.py:152) drop it
+  const bool active = live && !ghost;
+  if (active) {
+    const int self = i - tl.a0;
+    idn = idi;
+    if (in_lds)
+      pass_b_body<NOISE, true>(w, tl, tile, i, self, C, Cn, ws, idi, js, x, y, vx, vy, eta, offById, P, sx, sy, wrec, xn,
+                               yn, vxn, vyn);
+    else
+      pass_b_body<NOISE, false>(w, tl, tile, i, self, C, Cn, ws, idi, js, x, y, vx, vy, eta, offById, P, sx, sy, wrec, xn,
+                                yn, vxn, vyn);
   }
-  const int self = i - tl.a0;
-  if (in_lds)
-    pass_b_body<NOISE, true>(w, tl, tile, i, self, C, Cn, ws, idi, js, x, y, vx, vy, eta, offById, P, sx, sy, wrec, xo, yo,
-                             vxo, vyo, ido);
-  else
-    pass_b_body<NOISE, false>(w, tl, tile, i, self, C, Cn, ws, idi, js, x, y, vx, vy, eta, offById, P, sx, sy, wrec, xo,
-                              yo, vxo, vyo, ido);
+  if (FUSED) {
+    int cnext = -1, wsn = -1;
+    if (active) cnext = wall_and_cell(wn, xn, yn, wsn, counters, wrec_counter_next, wrec_next);
+    if (live) {
+      cellS[i] = cnext;
+      if (cnext >= 0) wslotS[i] = wsn;
+    }
+    count_cells(cnext, cellCount);  // every lane of the wave takes part
+  }
+  if (live) {
+    xo[i] = xn;
+    yo[i] = yn;
+    vxo[i] = vxn;
+    vyo[i] = vyn;
+    ido[i] = idn;
+  }
 }
 
 }  // namespace sc

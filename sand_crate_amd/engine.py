@@ -109,6 +109,21 @@ class Engine:
             arr[k] = N.Body(pos[0], pos[1], vel[0], vel[1], float(omega), int(nseg), 0)
         N.check(self._lib.sc_set_segments(self._ctx, N.dptr(seg), N.dptr(pad), len(seg), arr, len(bodies)))
 
+    def set_next_inputs(self, *, gravity, segments, bodies, **coef) -> None:
+        """Promise the inputs of the next tick (between step_begin and step_finish); see the header."""
+        g = np.asarray(gravity, dtype=np.float64).reshape(2)
+        p = N.Params(*(float(coef[k]) for k in ("dt", "particle_radius", "wall_collision_decay", "pressure_amplifier",
+                                               "ignored_pressure", "collider_noise_level", "viscosity",
+                                               "surface_smoothing", "target_pressure")), float(g[0]), float(g[1]))
+        seg = N.f64(segments).reshape(-1, 2, 2)
+        bodies = list(bodies)
+        arr = (N.Body * max(len(bodies), 1))()
+        for k, (pos, vel, omega, nseg) in enumerate(bodies):
+            pos = np.asarray(pos, dtype=np.float64).reshape(2)
+            vel = np.asarray(vel, dtype=np.float64).reshape(2)
+            arr[k] = N.Body(pos[0], pos[1], vel[0], vel[1], float(omega), int(nseg), 0)
+        N.check(self._lib.sc_set_next_inputs(self._ctx, C.byref(p), N.dptr(seg), len(seg), arr, len(bodies)))
+
     def set_noise_mode(self, mode: int, seed: int = 0) -> None:
         N.check(self._lib.sc_set_noise_mode(self._ctx, int(mode), int(seed) & (2 ** 64 - 1)))
 

@@ -509,3 +509,60 @@ def test_crate_grows_beyond_its_initial_capacity(sc):
     crate.particle_velocities = np.zeros_like(pts)
     crate.physics_tick()
     assert crate.particle_count == 500
+
+
+# ------------------------------------------------------------------ look-ahead (fused next-tick wall pass)
+@pytest.mark.parametrize("margin,vel", [(0.02, 0.1), (0.0, 25.0)])
+def test_run_with_lookahead_equals_tick_by_tick(sc, margin, vel):
+    """Crate.run(k) promises every next tick's inputs (sc_set_next_inputs), so pass B also does the next
+    tick's removal / wall contacts / wall fix / bucket counts.  It must be the same computation as k
+    separate physics_tick() calls, bit for bit -- with a moving wall, wall contacts and removals."""
+    n = 30000
+    p, v, d = synthetic(n, seed=21, margin=margin, vel=vel)
+    a = sc.Crate(wave_world(sc, d, 0.1), noise="counter", noise_seed=5, capacity=n + 16)
+    b = sc.Crate(wave_world(sc, d, 0.1), noise="counter", noise_seed=5, capacity=n + 16)
+    for c in (a, b):
+        c.particles = p
+        c.particle_velocities = v
+    a.run(7)
+    for _ in range(7):
+        b.physics_tick()
+    pa, va, pra, ida = a.engine.download()
+    pb, vb, prb, idb = b.engine.download()
+    assert np.array_equal(ida, idb)
+    assert np.array_equal(pa, pb) and np.array_equal(va, vb) and np.array_equal(pra, prb)
+    assert np.array_equal(a.segments, b.segments) and a.tick == b.tick == 7
+    # and the two styles can be mixed
+    a.physics_tick()
+    b.run(1)
+    assert np.array_equal(a.engine.download()[0], b.engine.download()[0])
+
+
+def test_lookahead_promise_is_binding(sc):
+    from sand_crate_amd import _native as N
+    wc = wave_world(sc, 0.02, 0.0)
+    crate = sc.Crate(wc, noise="none")
+    rs = np.random.RandomState(0)
+    pts = rs.rand(200, 2) * 0.8 + 0.1
+    crate.particles = pts
+    crate.particle_velocities = np.zeros_like(pts)
+    eng = crate.engine
+    crate._send_tick_inputs()
+    eng.step_begin()
+    coef = {name: getattr(crate, name) for name in ("dt", "particle_radius", "wall_collision_decay", "pressure_amplifier",
+                                                    "ignored_pressure", "collider_noise_level", "viscosity",
+                                                    "surface_smoothing", "target_pressure")}
+    bodies = [(b.position, b.center_velocity, b.angular_clockwise_velocity, len(b)) for b in crate.rigid_bodies]
+    eng.set_next_inputs(gravity=crate.gravity, segments=crate.segments, bodies=bodies, **coef)
+    eng.step_finish()
+    with pytest.raises(N.NativeError, match="promised"):
+        eng.append(np.array([[0.5, 0.5]]), np.zeros((1, 2)))       # no new particles before the promised tick
+    crate.particle_radius = 0.011                                    # different walls/grid than promised
+    crate._send_tick_inputs()
+    with pytest.raises(N.NativeError, match="promised"):
+        eng.step_begin()
+    crate.particle_radius = 0.01
+    crate._send_tick_inputs()
+    eng.step_begin()                                                 # the promised inputs: fine
+    eng.step_finish()
+    assert eng.count() == 200
