@@ -24,6 +24,8 @@
 // (about 12 instructions per candidate), and the pair math uses v_rsq_f64 + Newton steps instead of
 // an IEEE sqrt and divide.
 #pragma once
+#include <climits>
+
 #include "sc_kernels.h"
 
 namespace sc {
@@ -75,8 +77,8 @@ __device__ __forceinline__ int tile_of_block() {
 
 // Phases 3-5 of pass A for one particle.  LDS: where the tile is (compile time, see the header).
 template <int NOISE, bool ENUM, bool DENS, bool LDS>
-__device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, const int total, const XY* txy,
-                                            unsigned short (*list)[kTileW + 2], const int t, const int i,
+__device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, const int total, XY* txy,
+                                            unsigned short (*list)[kTileW + 2], int* wkey, const int t, const int i,
                                             const bool live, const int idi, const int e0, const int b0, const int b1,
                                             const int e1, const int bm, const int em, const double* __restrict__ x,
                                             const double* __restrict__ y, int* __restrict__ nbr,
@@ -95,51 +97,137 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
 
   // 3. neighbor list of particle i: four serial scans in the reference's order, entries are tile slots
   int C = 0;
+  int round = 0, rws = -(1 << 30);  // windowed search: round counter, first slot of the resident window
   const int self = i - tl.a0;
   XY pi = {0.0, 0.0};
   if (live) pi = load_xy(self);
   if (ENUM) {
-    if (live && slots_fit) {
+    if (slots_fit && (LDS ? live : true)) {
       const double xi = pi.x, yi = pi.y;
-      const double xhi = xi + w.d, xlo = xi - w.d;
-      // one scan: `count` candidates from tile slot `first`, walking by `step`; window() says
-      // 0 = stop the scan, 1 = outside the window, 2 = inside
-      // From LDS candidates are fetched one by one; from global memory (a tile too large for LDS)
-      // four at a time, so that the cold-miss latency is paid once per four.  Either way they are
-      // examined one by one, in order, with the reference's stop and window conditions.
-      constexpr int kFetch = LDS ? 1 : 4;
-      auto scan = [&](int first, int count, int step, auto window) {
-        bool done = false;
-        for (int v0 = 0; v0 < count && !done; v0 += kFetch) {
-          XY q[kFetch];
-#pragma unroll
-          for (int k = 0; k < kFetch; ++k) q[k] = load_xy(v0 + k < count ? first + (v0 + k) * step : self);
-#pragma unroll
-          for (int k = 0; k < kFetch; ++k) {
-            if (done || v0 + k >= count) continue;
-            const int verdict = window(q[k].x);
+      // One scan: `count` candidates from tile slot `first`, walking by `step`, examined one by one in
+      // order with the reference's window conditions: window(xj, xi) says 0 = stop the scan, 1 =
+      // outside the window, 2 = inside.
+      //   LDS tile: straight from the tile.
+      //   Tile too large for LDS (a block in or next to a pile-up; all threads of the block take
+      //   part): the workgroup moves a window of kTileCapA slots over the tile, placed on a grid of
+      //   half windows around the unfinished thread that is furthest behind, staged with coalesced
+      //   loads and kept for as long as somebody has candidates inside (a tile a little over the
+      //   LDS budget needs two windows for all four scans).  Inside a window a thread first walks
+      //   kSerial of its own candidates; ranges longer than that (a sparse particle walking a whole
+      //   pile in the next row, hardly a hit among thousands) are then taken one owner at a time
+      //   by the whole wave, 64 candidates per step, hits ranked by lane = scan order.  Every
+      //   particle still sees its candidates in the reference's order, so the lists are the same.
+      constexpr int kHalf = kTileCapA / 2, kSerial = 32;
+      auto scan = [&](bool want, int first, int count, int step, auto window) {
+        if constexpr (LDS) {
+          if (!want) return;
+          bool done = false;
+          for (int v = 0; v < count && !done; ++v) {
+            const int slot = first + v * step;
+            const XY q = txy[slot];
+            const int verdict = window(q.x, xi);
             if (verdict == 0) {
               done = true;
             } else if (verdict == 2) {
-              const double dx = q[k].x - xi, dy = q[k].y - yi;
+              const double dx = q.x - xi, dy = q.y - yi;
               if (dx * dx + dy * dy <= w.t_nbr) {  // norm(p_j - p_i) <= d (collision_detector.py:78-79)
-                list[C][t] = (unsigned short)(first + (v0 + k) * step);
+                list[C][t] = (unsigned short)slot;
                 if (++C == kMaxNbr) done = true;   // trim (:91-93)
               }
+            }
+          }
+        } else {
+          const int lane = t & 63, wave0 = t & ~63;
+          int pos = first, left = want ? count : 0;
+          for (;;) {
+            // the unfinished position that is furthest behind, block-wide (keys double-buffered by round)
+            int key = left > 0 ? pos * step : INT_MAX;
+            for (int o = 32; o > 0; o >>= 1) key = min(key, __shfl_down(key, o, 64));
+            int* wk = wkey + (round & 1) * (kTileW / 64);
+            ++round;
+            if (lane == 0) wk[t >> 6] = key;
+            __syncthreads();
+            int k0 = wk[0];
+#pragma unroll
+            for (int k = 1; k < kTileW / 64; ++k) k0 = min(k0, wk[k]);
+            if (k0 == INT_MAX) break;  // uniform: nobody has candidates left in this range
+            const int p0 = k0 * step;
+            if ((unsigned)(p0 - rws) >= (unsigned)kTileCapA) {  // not in the resident window: stage the one around it
+              rws = step > 0 ? (p0 / kHalf) * kHalf : max(0, (p0 / kHalf - 1) * kHalf);
+              constexpr int kPer = kTileCapA / kTileW;
+              XY r[kPer];
+#pragma unroll
+              for (int k = 0; k < kPer; ++k) {
+                const int slot = rws + t + k * kTileW;
+                if (slot < total) {
+                  const int j = tile_index(tl, slot);
+                  r[k] = XY{x[j], y[j]};
+                }
+              }
+#pragma unroll
+              for (int k = 0; k < kPer; ++k)
+                if (rws + t + k * kTileW < total) txy[t + k * kTileW] = r[k];
+              __syncthreads();
+            }
+            const int ws = rws;
+            auto inside = [&](int p) { return (unsigned)(p - ws) < (unsigned)kTileCapA; };
+            for (int b = 0; b < kSerial && left > 0 && inside(pos); ++b) {
+              const XY q = txy[pos - ws];
+              const int verdict = window(q.x, xi);
+              bool over = verdict == 0;
+              if (verdict == 2) {
+                const double dx = q.x - xi, dy = q.y - yi;
+                if (dx * dx + dy * dy <= w.t_nbr) {
+                  list[C][t] = (unsigned short)pos;
+                  over = ++C == kMaxNbr;
+                }
+              }
+              pos += step;
+              left = over ? 0 : left - 1;
+            }
+            unsigned long long m = __ballot(left > 0 && inside(pos));
+            while (m) {
+              const int owner = __ffsll(m) - 1;
+              const int opos = __shfl(pos, owner, 64), oleft = __shfl(left, owner, 64), oC = __shfl(C, owner, 64);
+              const double oxi = __shfl(xi, owner, 64), oyi = __shfl(yi, owner, 64);
+              const int avail = step > 0 ? ws + kTileCapA - opos : opos - ws + 1;  // slots of the window from opos on
+              const int nc = min(min(oleft, avail), 64);
+              const int slot = opos + lane * step;
+              int verdict = 1;
+              bool hit = false;
+              if (lane < nc) {
+                const XY q = txy[slot - ws];
+                verdict = window(q.x, oxi);
+                const double dx = q.x - oxi, dy = q.y - oyi;
+                hit = verdict == 2 && dx * dx + dy * dy <= w.t_nbr;
+              }
+              const unsigned long long stopm = __ballot(verdict == 0);
+              const int nlive = stopm ? __ffsll(stopm) - 1 : nc;  // candidates ahead of the stop
+              const unsigned long long hitm = __ballot(hit && lane < nlive);
+              const int need = kMaxNbr - oC;
+              const int rank = __popcll(hitm & ((1ull << lane) - 1ull));
+              if (hit && lane < nlive && rank < need) list[oC + rank][wave0 + owner] = (unsigned short)slot;
+              const int nh = min((int)__popcll(hitm), need);
+              if (lane == owner) {
+                C = oC + nh;
+                pos = opos + nc * step;
+                left = (stopm != 0 || nh == need) ? 0 : oleft - nc;
+              }
+              m = __ballot(left > 0 && inside(pos));
             }
           }
         }
       };
       // same strip, after i: x_j <= x_i + d                                  (:106-109)
-      scan(self + 1, e0 - (i + 1), 1, [&](double xj) { return xj > xhi ? 0 : 2; });
+      scan(live, self + 1, e0 - (i + 1), 1, [&](double xj, double xq) { return xj > xq + w.d ? 0 : 2; });
       // next strip: x_i - d <= x_j <= x_i + d                                (:112-119)
-      if (C < kMaxNbr) scan(tl.n0 + (b1 - tl.a1), e1 - b1, 1, [&](double xj) { return xj > xhi ? 0 : (xj >= xlo ? 2 : 1); });
+      scan(live && C < kMaxNbr, tl.n0 + (b1 - tl.a1), e1 - b1, 1,
+           [&](double xj, double xq) { return xj > xq + w.d ? 0 : (xj >= xq - w.d ? 2 : 1); });
       // reverse edges (:85-88): i is a forward candidate of j, same strip
-      if (C < kMaxNbr) scan(self - 1, i - b0, -1, [&](double xj) { return !(xi <= xj + w.d) ? 0 : 2; });
+      scan(live && C < kMaxNbr, self - 1, i - b0, -1, [&](double xj, double xq) { return !(xq <= xj + w.d) ? 0 : 2; });
       // reverse edges from the previous strip
-      if (C < kMaxNbr)
-        scan(tl.n0 + tl.n1 + (em - 1 - tl.a2), em - bm, -1,
-             [&](double xj) { return !(xi <= xj + w.d) ? 0 : (xi >= xj - w.d ? 2 : 1); });
+      scan(live && C < kMaxNbr, tl.n0 + tl.n1 + (em - 1 - tl.a2), em - bm, -1,
+           [&](double xj, double xq) { return !(xq <= xj + w.d) ? 0 : (xq >= xj - w.d ? 2 : 1); });
     } else if (live) {
       // a tile beyond 65535 particles (a block inside one gigantic bucket) cannot use u16 slots:
       // entries go straight to the table as -(index+1); correctness path only
@@ -255,6 +343,7 @@ __global__ void __launch_bounds__(kTileW)
   __shared__ XY txy[kTileCapA];
   __shared__ unsigned short list[kMaxNbr][kTileW + 2];  // tile slots of the neighbors, [slot][thread]
   __shared__ int bounds[6];
+  __shared__ int wkey[2 * (kTileW / 64)];
 
   const int t = threadIdx.x;
   const int tile_id = tile_of_block();
@@ -323,10 +412,10 @@ __global__ void __launch_bounds__(kTileW)
   if (ENUM && t < 6) tileBounds[6 * tile_id + t] = bounds[t];  // pass B stages the same three ranges
 
   if (in_lds)
-    pass_a_body<NOISE, ENUM, DENS, true>(w, tl, total, txy, list, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr, cnt,
+    pass_a_body<NOISE, ENUM, DENS, true>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr, cnt,
                                          cap, eta, offById, P, sx, sy);
   else
-    pass_a_body<NOISE, ENUM, DENS, false>(w, tl, total, txy, list, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr,
+    pass_a_body<NOISE, ENUM, DENS, false>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr,
                                           cnt, cap, eta, offById, P, sx, sy);
 }
 

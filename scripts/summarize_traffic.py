@@ -31,6 +31,7 @@ kf, kw = GiB / cal_f, GiB / cal_w  # true bytes per counted byte, 8 B per lane c
 fetch = per_kernel(f"{out_dir}/bench_FETCH_SIZE", "FETCH_SIZE")
 write = per_kernel(f"{out_dir}/bench_WRITE_SIZE", "WRITE_SIZE")
 names = {"sc::k_wall_bin": "wall_bin", "sc::k_scan_local": "cell_scan(local)", "sc::k_scan_fix": "cell_scan(fix)",
+         "sc::k_scan_cells": "cell_scan", "sc::k_sort_big": "sort_big",
          "sc::k_scatter": "scatter", "sc::k_reorder": "reorder"}
 res = {"particles": n, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, --kernel-trace only; unit KiB",
        "calibration": {"kernel": "float64 copy, 8 B per lane, 1 GiB read + 1 GiB written (scripts/traffic_calib.hip)",

@@ -397,6 +397,35 @@ def test_pile_up_buckets_sort_and_rank(sc):
     assert np.array_equal(table, ref_table)
 
 
+@pytest.mark.parametrize("seed", [11, 12])
+def test_dense_regions_windowed_search(sc, seed):
+    """Tiles too large for LDS are searched through a sliding window; every kind of scan must keep the
+    reference's order: piles spread over x and y (partial hits), sparse particles that walk a
+    whole pile in the next / previous row with hardly a hit, piles that span several rows and columns,
+    a tile that ends inside a pile."""
+    from oracle.neighbors import neighbor_lists, strip_sort
+    rs = np.random.RandomState(seed)
+    d = 0.04
+    parts = [
+        np.column_stack((0.40 + rs.rand(1300) * d * 2.2, 0.40 + rs.rand(1300) * d * 0.98)),     # 2+ cells wide, one row
+        np.column_stack((0.40 + rs.rand(40) * d * 3.0, 0.40 + d + rs.rand(40) * d)),            # sparse row below it
+        np.column_stack((0.40 + rs.rand(40) * d * 3.0, 0.40 - d + rs.rand(40) * d)),            # sparse row above it
+        np.column_stack((0.12 + rs.rand(900) * d * 0.5, 0.08 + rs.rand(900) * d * 3.0)),        # a tall pile: 3 rows
+        np.column_stack((0.80 + rs.rand(700) * 1e-9, 0.20 + rs.rand(700) * d * 0.2)),           # near-ties in x
+        np.column_stack((0.80 + rs.rand(600) * d, 0.20 + d + rs.rand(600) * d)),                # dense row under the ties
+        rs.rand(2500, 2) * 0.9 + 0.02,
+    ]
+    pts = np.vstack(parts)
+    pts = pts[rs.permutation(len(pts))]
+    rows, order, counts, table = sc.neighbor_search(pts, d)
+    ref_rows, ref_order = strip_sort(pts, d)
+    assert np.array_equal(order, ref_order)
+    ref_counts, ref_table = neighbor_lists(pts, d)
+    assert np.array_equal(counts, ref_counts)
+    assert np.array_equal(table, ref_table)
+    assert (counts < 20).sum() > 1000 and (counts == 20).sum() > 2000
+
+
 def test_pile_up_state_ticks_with_bucket_sort(sc):
     """The same through the tick path: the second tick is launched with the big-bucket hint set."""
     rs = np.random.RandomState(4)
