@@ -31,7 +31,9 @@
 namespace sc {
 
 constexpr int kTileW = 128;      // particles (= threads) per workgroup
-constexpr int kTileCapA = 512;   // pass A tile: (x, y) records, 8 KiB
+// pass A tile, (x, y) records: 8 KiB when many workgroups share a CU (more waves in flight), 12 KiB when the
+// whole grid is resident anyway (fewer tiles fall out of LDS); the launcher picks (measured: profiles/)
+constexpr int kTileCapA = 512, kTileCapAWide = 768;
 constexpr int kTileCapB = 480;   // pass B tile: (x, y, vx, vy, P, sx, sy, -) records, 30 KiB
 constexpr int kSlotMax = 65535;  // lists are staged as u16 tile slots in pass A
 
@@ -76,7 +78,7 @@ __device__ __forceinline__ int tile_of_block() {
 }
 
 // Phases 3-5 of pass A for one particle.  LDS: where the tile is (compile time, see the header).
-template <int NOISE, bool ENUM, bool DENS, bool LDS>
+template <int NOISE, bool ENUM, bool DENS, bool LDS, int CAP>
 __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, const int total, XY* txy,
                                             unsigned short (*list)[kTileW + 2], int* wkey, const int t, const int i,
                                             const bool live, const int idi, const int e0, const int b0, const int b1,
@@ -109,7 +111,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       // outside the window, 2 = inside.
       //   LDS tile: straight from the tile.
       //   Tile too large for LDS (a block in or next to a pile-up; all threads of the block take
-      //   part): the workgroup moves a window of kTileCapA slots over the tile, placed on a grid of
+      //   part): the workgroup moves a window of CAP slots over the tile, placed on a grid of
       //   half windows around the unfinished thread that is furthest behind, staged with coalesced
       //   loads and kept for as long as somebody has candidates inside (a tile a little over the
       //   LDS budget needs two windows for all four scans).  Inside a window a thread first walks
@@ -117,7 +119,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       //   pile in the next row, hardly a hit among thousands) are then taken one owner at a time
       //   by the whole wave, 64 candidates per step, hits ranked by lane = scan order.  Every
       //   particle still sees its candidates in the reference's order, so the lists are the same.
-      constexpr int kHalf = kTileCapA / 2, kSerial = 32;
+      constexpr int kHalf = CAP / 2, kSerial = 32;
       auto scan = [&](bool want, int first, int count, int step, auto window) {
         if constexpr (LDS) {
           if (!want) return;
@@ -152,9 +154,9 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
             for (int k = 1; k < kTileW / 64; ++k) k0 = min(k0, wk[k]);
             if (k0 == INT_MAX) break;  // uniform: nobody has candidates left in this range
             const int p0 = k0 * step;
-            if ((unsigned)(p0 - rws) >= (unsigned)kTileCapA) {  // not in the resident window: stage the one around it
+            if ((unsigned)(p0 - rws) >= (unsigned)CAP) {  // not in the resident window: stage the one around it
               rws = step > 0 ? (p0 / kHalf) * kHalf : max(0, (p0 / kHalf - 1) * kHalf);
-              constexpr int kPer = kTileCapA / kTileW;
+              constexpr int kPer = CAP / kTileW;
               XY r[kPer];
 #pragma unroll
               for (int k = 0; k < kPer; ++k) {
@@ -170,7 +172,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
               __syncthreads();
             }
             const int ws = rws;
-            auto inside = [&](int p) { return (unsigned)(p - ws) < (unsigned)kTileCapA; };
+            auto inside = [&](int p) { return (unsigned)(p - ws) < (unsigned)CAP; };
             for (int b = 0; b < kSerial && left > 0 && inside(pos); ++b) {
               const XY q = txy[pos - ws];
               const int verdict = window(q.x, xi);
@@ -190,7 +192,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
               const int owner = __ffsll(m) - 1;
               const int opos = __shfl(pos, owner, 64), oleft = __shfl(left, owner, 64), oC = __shfl(C, owner, 64);
               const double oxi = __shfl(xi, owner, 64), oyi = __shfl(yi, owner, 64);
-              const int avail = step > 0 ? ws + kTileCapA - opos : opos - ws + 1;  // slots of the window from opos on
+              const int avail = step > 0 ? ws + CAP - opos : opos - ws + 1;  // slots of the window from opos on
               const int nc = min(min(oleft, avail), 64);
               const int slot = opos + lane * step;
               int verdict = 1;
@@ -333,14 +335,14 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
 // indexed after all counts are known: then <ENUM only> runs in sc_step_begin and <DENS only> in
 // sc_step_finish.
 // ------------------------------------------------------------------------------------------
-template <int NOISE, bool ENUM, bool DENS>
+template <int NOISE, bool ENUM, bool DENS, int CAP>
 __global__ void __launch_bounds__(kTileW)
     k_pass_a(World w, const int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
              const int* __restrict__ id, const int* __restrict__ cell, Buckets bk,
              int* __restrict__ nbr, unsigned char* __restrict__ cnt, int cap, const double* __restrict__ eta,
              const int* __restrict__ offById, double* __restrict__ P, double* __restrict__ sx,
              double* __restrict__ sy, int* __restrict__ tileBounds) {
-  __shared__ XY txy[kTileCapA];
+  __shared__ XY txy[CAP];
   __shared__ unsigned short list[kMaxNbr][kTileW + 2];  // tile slots of the neighbors, [slot][thread]
   __shared__ int bounds[6];
   __shared__ int wkey[2 * (kTileW / 64)];
@@ -388,11 +390,11 @@ __global__ void __launch_bounds__(kTileW)
   tl.a2 = bounds[4];
   tl.n2 = bounds[5] - tl.a2;
   const int total = tl.n0 + tl.n1 + tl.n2;
-  const bool in_lds = total <= kTileCapA;
+  const bool in_lds = total <= CAP;
 
   // 2. stage (x, y) of the three ranges; every load of the tile is in flight before the first LDS write
   if (in_lds) {
-    constexpr int kPer = kTileCapA / kTileW;
+    constexpr int kPer = CAP / kTileW;
     XY r[kPer];
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
@@ -412,10 +414,10 @@ __global__ void __launch_bounds__(kTileW)
   if (ENUM && t < 6) tileBounds[6 * tile_id + t] = bounds[t];  // pass B stages the same three ranges
 
   if (in_lds)
-    pass_a_body<NOISE, ENUM, DENS, true>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr, cnt,
+    pass_a_body<NOISE, ENUM, DENS, true, CAP>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr, cnt,
                                          cap, eta, offById, P, sx, sy);
   else
-    pass_a_body<NOISE, ENUM, DENS, false>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr,
+    pass_a_body<NOISE, ENUM, DENS, false, CAP>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr,
                                           cnt, cap, eta, offById, P, sx, sy);
 }
 

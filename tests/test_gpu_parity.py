@@ -397,13 +397,14 @@ def test_pile_up_buckets_sort_and_rank(sc):
     assert np.array_equal(table, ref_table)
 
 
-@pytest.mark.parametrize("seed", [11, 12])
-def test_dense_regions_windowed_search(sc, seed):
+@pytest.mark.parametrize("seed,tile", [(11, "narrow"), (12, "wide")])
+def test_dense_regions_windowed_search(sc, seed, tile, monkeypatch):
     """Tiles too large for LDS are searched through a sliding window; every kind of scan must keep the
     reference's order: piles spread over x and y (partial hits), sparse particles that walk a
     whole pile in the next / previous row with hardly a hit, piles that span several rows and columns,
     a tile that ends inside a pile."""
     from oracle.neighbors import neighbor_lists, strip_sort
+    monkeypatch.setenv("SANDCRATE_TILE", tile)  # read by sc_create: both pass A tile sizes, whatever the grid
     rs = np.random.RandomState(seed)
     d = 0.04
     parts = [
