@@ -82,11 +82,12 @@ struct sc_ctx {
   int* tileBounds = nullptr;
   int *cellCount = nullptr, *cellStart = nullptr, *blockSums = nullptr, *blockOff = nullptr, *sortedStamp = nullptr;
   int* bigList = nullptr;
+  int* rankAcc = nullptr;  // per bucket slot: rank inside a big bucket (k_rank_big adds, k_reorder takes and clears)
   // host-mapped progress block written by the GPU, read by the host without synchronisation:
   // [0] big buckets seen by the last finished scan, [1] ticks finished
   int* bigHintHost = nullptr;
   int* bigHintDev = nullptr;
-  bool force_sort_big = false;
+  bool force_rank_big = false;
   int64_t cellAlloc = 0;
   double* wrec[2] = {nullptr, nullptr};  // wall records of even / odd ticks
   int* nbr = nullptr;
@@ -472,9 +473,8 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
   if (e == hipSuccess) e = dalloc(&c->keyId, n);
   if (e == hipSuccess) e = dalloc(&c->tileBounds, 6 * (n / kTileW + 2));
   if (e == hipSuccess) e = dalloc(&c->bigList, (size_t)kMaxBig);
-  if (e == hipSuccess)  // k_sort_big stages up to kSortCap (x, id, perm) triples: 128 KiB of dynamic LDS
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_big), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(kSortCap * (sizeof(double) + 2 * sizeof(int))));
+  if (e == hipSuccess) e = dalloc(&c->rankAcc, n);
+  if (e == hipSuccess) e = hipMemsetAsync(c->rankAcc, 0, n * sizeof(int), c->stream);
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->bigHintHost, 2 * sizeof(int), hipHostMallocMapped);
   if (e == hipSuccess) {
     c->bigHintHost[0] = c->bigHintHost[1] = 0;
@@ -509,7 +509,7 @@ int sc_destroy(sc_ctx* c) {
     (void)hipFree(c->vy[s]);
     (void)hipFree(c->id[s]);
   }
-  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->wrec[0], c->wrec[1],
+  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->rankAcc, c->wrec[0], c->wrec[1],
                   c->nbr, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
                   c->stage_xy, c->stage_vxy, c->owned_out};
   for (void* p : ptrs)
@@ -663,19 +663,18 @@ int sc_step_begin(sc_ctx* c) {
   }
   const int stamp = (int)((c->tick + 1) & 0x3FFFFFFF);
   // big buckets were seen by the last scan the host knows about (an unsynchronised, possibly stale
-  // hint in host-mapped memory): sort this tick's big buckets properly before ranking
-  if (c->force_sort_big || *(volatile int*)c->bigHintHost > 0) {
+  // hint in host-mapped memory): rank this tick's big buckets over the whole GPU first
+  if (c->force_rank_big || *(volatile int*)c->bigHintHost > 0) {
     Bracket br(c, K_SCAN);
-    hipLaunchKernelGGL(k_sort_big, dim3(64), dim3(kSortBlock), kSortCap * (sizeof(double) + 2 * sizeof(int)), c->stream,
-                       c->counters, c->bigList, Buckets{c->cellStart, c->blockOff}, c->keyX, c->keyId, c->perm,
-                       c->sortedStamp, stamp);
+    hipLaunchKernelGGL(k_rank_big, dim3(4 * c->num_cus), dim3(kRankTile), 0, c->stream, c->counters, c->bigList,
+                       Buckets{c->cellStart, c->blockOff}, c->keyX, c->keyId, c->rankAcc, c->sortedStamp, stamp);
   }
   {
     Bracket br(c, K_REORDER);
     hipLaunchKernelGGL(k_reorder, dim3((int)std::max<int64_t>(1, (launch_bound(c) + kReorderBlock - 1) / kReorderBlock)),
                        dim3(kReorderBlock), 0, c->stream, c->counters, c->perm, c->keyX, c->keyId,
                        c->cellS, Buckets{c->cellStart, c->blockOff}, c->wslotS, c->y[0], c->vx[0], c->vy[0], c->x[1], c->y[1], c->vx[1],
-                       c->vy[1], c->id[1], c->cellT, c->wslotT, c->sortedStamp, stamp);
+                       c->vy[1], c->id[1], c->cellT, c->wslotT, c->sortedStamp, stamp, c->rankAcc);
   }
   // SC_NOISE_HOST (and the stand-alone search) stop after the lists: the host's rand block can only be
   // indexed once every count is known.  Otherwise the search and pass A are one launch.
@@ -995,7 +994,7 @@ int sc_neighbor_search(int device, const double* xy, int64_t n, double diameter,
   int rc = sc_create(device, n, &c);
   if (rc) return rc;
   c->custom_grid = true;
-  c->force_sort_big = true;  // no previous tick to take the hint from
+  c->force_rank_big = true;  // no previous tick to take the hint from
   c->custom_d = diameter;
   c->grid_row0 = (long long)r0 - 1;
   c->grid_col0 = (long long)c0 - 1;

@@ -243,8 +243,7 @@ __global__ void __launch_bounds__(kBlock) k_scan_fix(int* __restrict__ out, int 
 // 2048-cell block (cellStart) and the start of the block (blockOff) -- so that no second pass over
 // the cells is needed: every workgroup scans its block, and the last one to finish (ticket) scans
 // the block totals.  Readers add the two (struct Buckets).  Saves a ~5 us launch per tick.
-constexpr int kSortThreshold = 96;  // buckets above this many particles are sorted by k_sort_big
-constexpr int kSortCap = 8192;      // ... up to this many (128 KiB of LDS); larger ones keep the k^2 ranking
+constexpr int kSortThreshold = 96;  // buckets above this many particles are listed for k_rank_big
 constexpr int kMaxBig = 4096;       // room in the list of big buckets
 constexpr int kScanShift = 11;
 static_assert((1 << kScanShift) == kScanPerBlock, "block offset lookup assumes 2048 cells per scan block");
@@ -326,71 +325,104 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
     counters[C_NT] = carry;  // live particles = entries of the sorted arrays
     counters[C_TICKET] = 0;
     // a hint for the host, in host-mapped memory: were there big buckets?  It is read without any
-    // synchronisation when the NEXT tick is enqueued and only decides whether k_sort_big is launched.
+    // synchronisation when the NEXT tick is enqueued and only decides whether k_rank_big is launched.
     bigHint[0] = __hip_atomic_load(&counters[C_NBIG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// K3b  sort of big buckets.  Ranking a bucket of k particles inside K4 costs k^2 compares, which is
-// what a pile of thousands of particles stopped on a wall -- all with exactly the same x -- turns
-// into hundreds of microseconds.  Buckets listed by the scan are instead sorted here by (x, id) with
-// a bitonic network in LDS, written back in order and stamped; K4 then takes rank = slot - start.
-// Fixed small grid, one workgroup per bucket at a time.  Launched only when the previous tick saw
-// big buckets; without it K4 falls back to its cooperative k^2 ranking.
+// K3b  ranks inside big buckets.  Ranking a bucket of k particles costs k^2 compares; done inside K4
+// by the few workgroups that hold the bucket, a pile of thousands of particles in one cell (stopped
+// in a corner by the continuous-collision fix, many with exactly equal x) takes hundreds of
+// microseconds.  Here the k^2 compares of every bucket the scan listed are cut into tasks of
+// kRankTile x kRankTile and dealt over the whole GPU; a task counts, for its kRankTile particles, the
+// keys of its chunk that are smaller by (x, id) and adds that to the particle's slot in rankAcc.
+// The bucket is stamped; K4 takes the rank from rankAcc (and clears it).  Launched only when the
+// previous tick saw big buckets; a bucket that is not stamped is ranked inside K4 as before.
 // ------------------------------------------------------------------------------------------
-constexpr int kSortBlock = 1024;  // 16 waves: the network is 91 dependent LDS stages, latency needs covering
+constexpr int kRankTile = 256;
+constexpr int kRankMaxBuckets = 1024;  // big buckets handled per tick (more: the rest is ranked in K4)
 
-__global__ void __launch_bounds__(kSortBlock)
-    k_sort_big(const int* __restrict__ counters, const int* __restrict__ bigList, Buckets bk, double* __restrict__ keyX,
-               int* __restrict__ keyId, int* __restrict__ perm, int* __restrict__ sortedStamp, int stamp) {
-  extern __shared__ double sort_lds[];
-  double* sx = sort_lds;                               // kSortCap doubles
-  int* si = reinterpret_cast<int*>(sx + kSortCap);     // kSortCap ints
-  int* sp = si + kSortCap;                             // kSortCap ints
-  const int nbig = min(__hip_atomic_load(&counters[C_NBIG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), kMaxBig);
-  for (int q = blockIdx.x; q < nbig; q += gridDim.x) {
-    const int c = bigList[q];
-    const int b = bk(c), k = bk(c + 1) - b;
-    if (k > kSortCap || k < 2) continue;
-    int n2 = 1;
-    while (n2 < k) n2 <<= 1;
+struct RankKey {
+  double x;
+  int id, pad;
+};
+
+__global__ void __launch_bounds__(kRankTile)
+    k_rank_big(const int* __restrict__ counters, const int* __restrict__ bigList, Buckets bk,
+               const double* __restrict__ keyX, const int* __restrict__ keyId, int* __restrict__ rankAcc,
+               int* __restrict__ sortedStamp, int stamp) {
+  __shared__ int pre[kRankMaxBuckets + 1];  // tasks before bucket q
+  __shared__ int bstart[kRankMaxBuckets], blen[kRankMaxBuckets];
+  __shared__ int waveTot[kRankTile / 64];
+  __shared__ RankKey chunk[kRankTile];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nbig = min(__hip_atomic_load(&counters[C_NBIG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), kRankMaxBuckets);
+  if (nbig == 0) return;
+  // every workgroup derives the same task table from the same list
+  constexpr int kPer = kRankMaxBuckets / kRankTile;
+  int tasks[kPer], sum = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int q = tid * kPer + k;
+    int t = 0;
+    if (q < nbig) {
+      const int c = bigList[q];
+      const int b = bk(c), len = bk(c + 1) - b;
+      const int tiles = (len + kRankTile - 1) / kRankTile;
+      bstart[q] = b;
+      blen[q] = len;
+      t = tiles * tiles;
+    }
+    tasks[k] = sum;
+    sum += t;
+  }
+  int incl = sum;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) waveTot[wv] = incl;
+  __syncthreads();
+  int wbase = 0, total = 0;
+  for (int k = 0; k < kRankTile / 64; ++k) {
+    if (k < wv) wbase += waveTot[k];
+    total += waveTot[k];
+  }
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int q = tid * kPer + k;
+    if (q <= nbig) pre[q] = wbase + incl - sum + tasks[k];
+  }
+  __syncthreads();
+  for (int task = blockIdx.x; task < total; task += gridDim.x) {
+    int lo = 0, hi = nbig;  // the bucket of this task: last q with pre[q] <= task
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (pre[mid] <= task) lo = mid; else hi = mid;
+    }
+    const int q = lo, local = task - pre[q];
+    const int b = bstart[q], len = blen[q];
+    const int tiles = (len + kRankTile - 1) / kRankTile;
+    const int ti = local / tiles, tj = local - ti * tiles;
+    const int j = tj * kRankTile + tid, i = ti * kRankTile + tid;
     __syncthreads();
-    for (int t = threadIdx.x; t < n2; t += kSortBlock) {
-      const bool in = t < k;
-      sx[t] = in ? keyX[b + t] : __builtin_huge_val();
-      si[t] = in ? keyId[b + t] : 0x7FFFFFFF;
-      sp[t] = in ? perm[b + t] : 0;
-    }
-    for (int size = 2; size <= n2; size <<= 1) {
-      for (int stride = size >> 1; stride > 0; stride >>= 1) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < (n2 >> 1); t += kSortBlock) {
-          const int i = 2 * t - (t & (stride - 1));
-          const int j = i + stride;
-          const bool up = (i & size) == 0;
-          const double xi = sx[i], xj = sx[j];
-          const int di = si[i], dj = si[j];
-          const bool gt = (xi > xj) || (xi == xj && di > dj);
-          if (gt == up) {
-            sx[i] = xj;
-            sx[j] = xi;
-            si[i] = dj;
-            si[j] = di;
-            const int pi = sp[i];
-            sp[i] = sp[j];
-            sp[j] = pi;
-          }
-        }
-      }
+    chunk[tid] = j < len ? RankKey{keyX[b + j], keyId[b + j], 0} : RankKey{__builtin_huge_val(), 0x7FFFFFFF, 0};
+    double xi = 0;
+    int idi = 0;
+    if (i < len) {
+      xi = keyX[b + i];
+      idi = keyId[b + i];
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < k; t += kSortBlock) {
-      keyX[b + t] = sx[t];
-      keyId[b + t] = si[t];
-      perm[b + t] = sp[t];
+    int r = 0;
+#pragma unroll 8
+    for (int k = 0; k < kRankTile; ++k) {
+      const RankKey o = chunk[k];
+      r += (o.x < xi) || (o.x == xi && o.id < idi);
     }
-    if (threadIdx.x == 0) sortedStamp[c] = stamp;
+    if (i < len && r) atomicAdd(&rankAcc[b + i], r);
+    if (local == 0 && tid == 0) sortedStamp[bigList[q]] = stamp;
   }
 }
 
@@ -441,7 +473,7 @@ __global__ void __launch_bounds__(kReorderBlock)
               const int* __restrict__ wslotS, const double* __restrict__ yS, const double* __restrict__ vxS,
               const double* __restrict__ vyS, double* __restrict__ xT, double* __restrict__ yT,
               double* __restrict__ vxT, double* __restrict__ vyT, int* __restrict__ idT, int* __restrict__ cellT,
-              int* __restrict__ wslotT, const int* __restrict__ sortedStamp, int stamp) {
+              int* __restrict__ wslotT, const int* __restrict__ sortedStamp, int stamp, int* __restrict__ rankAcc) {
   __shared__ double ckx[kRankChunk];
   __shared__ int cki[kRankChunk];
   __shared__ int pick;
@@ -463,9 +495,12 @@ __global__ void __launch_bounds__(kReorderBlock)
     e = bk(c + 1);
   }
   int rank = 0;
-  // a bucket k_sort_big has put in (x, id) order this tick: the slot is the rank
+  // a bucket k_rank_big has ranked this tick: take the rank and leave the accumulator clean
   const bool presorted = live && (e - b) > kSortThreshold && sortedStamp[c] == stamp;
-  if (presorted) rank = s - b;
+  if (presorted) {
+    rank = rankAcc[s];
+    rankAcc[s] = 0;
+  }
   const bool big = live && !presorted && (e - b) > kBigBucket;
   if (live && !big && !presorted) {
     for (int t = b; t < e; t += 4) {  // four keys in flight per round trip
