@@ -143,6 +143,18 @@ int sc_step_stats(sc_ctx* ctx, sc_stats* out);
 int sc_set_noise_host(sc_ctx* ctx, const double* u01, int64_t n_pairs);
 int sc_step_finish(sc_ctx* ctx);
 int sc_step(sc_ctx* ctx, int32_t n_ticks);
+/* One whole tick in ONE call, for drivers whose per-call overhead matters (ctypes: ~4 us per call):
+ *   sc_set_params(now) + sc_set_segments(now) + sc_step_begin + [sc_set_next_inputs(next)] + sc_step_finish.
+ * `next` may be NULL (no look-ahead).  Same errors as the calls it stands for; not valid in
+ * SC_NOISE_HOST mode (the host has to draw the noise between begin and finish, crate.py:169). */
+typedef struct sc_tick_inputs {
+  sc_params params;
+  const double* segments; /* n_segments x 2 x 2 (crate.py:69-71) */
+  const double* padded;   /* 2 n_segments x 2 x 2 (geometry_utils.py:146-172) */
+  const sc_body* bodies;
+  int32_t n_segments, n_bodies;
+} sc_tick_inputs;
+int sc_tick(sc_ctx* ctx, const sc_tick_inputs* now, const sc_tick_inputs* next);
 int sc_synchronize(sc_ctx* ctx);
 
 /* Parity taps, valid between sc_step_begin and sc_step_finish.  Synchronise.  All arrays have one
@@ -185,11 +197,19 @@ const char* sc_kernel_name(int index);
  *
  * Per tick:  sc_halo_pack -> exchange the two buffers with the neighbors (RCCL send/recv on
  * the stream given to sc_set_stream, or any transport) -> sc_halo_unpack of the two received buffers
- * (either pointer may be NULL at a domain edge) -> sc_step.  Buffers are DEVICE memory of (capacity_records + 1) * 5 doubles, caller-owned (e.g.
- * torch tensors): record 0 is a header whose first field is the record count, records 1.. are
- * (x, y, vx, vy, id).  sc_halo_pack writes every stored particle within `halo` columns of the
- * left / right edge, including particles that have already moved out of the slab on that side
- * (migrants: the receiver owns them from this tick on).  Nothing here synchronises. */
+ * (either pointer may be NULL at a domain edge) -> the tick.  Buffers are DEVICE memory of
+ * (capacity_records + 1) * 5 doubles, caller-owned (e.g. torch tensors) and zero-initialised: record 0 is
+ * a header whose first 32-bit word is the record count, records 1.. are (x, y, vx, vy, id).
+ * sc_halo_pack writes every stored particle within `halo` columns of the left / right edge, including
+ * particles that have already moved out of the slab on that side (migrants: the receiver owns them from
+ * this tick on).  sc_halo_unpack also re-arms the headers of the send buffers, which must therefore have
+ * been sent (in stream order) by then.  Nothing here synchronises.
+ *
+ * Look-ahead: the buffers given to the last sc_halo_pack stay bound to the context.  A tick whose successor
+ * was promised (sc_set_next_inputs / sc_tick with `next`) packs the successor's halo message in the epilogue
+ * of its force kernel, and the following sc_halo_unpack runs the removal / wall pass for what it appends; the
+ * steady-state slab tick is then:  exchange -> sc_halo_unpack -> sc_tick(now, next).  Calling sc_halo_pack
+ * for a tick that was packed this way is refused (SC_ERR_STATE). */
 int sc_set_slab(sc_ctx* ctx, int64_t col_lo, int64_t col_hi, int32_t halo, int32_t has_left, int32_t has_right);
 int sc_upload_state_ids(sc_ctx* ctx, const double* xy, const double* vxy, const int64_t* ids, int64_t n);
 int sc_halo_pack(sc_ctx* ctx, double* dev_left, double* dev_right, int64_t capacity_records);

@@ -37,6 +37,11 @@ class Body(C.Structure):
                 ("angular_clockwise_velocity", C.c_double), ("n_segments", C.c_int32), ("reserved", C.c_int32)]
 
 
+class TickInputs(C.Structure):
+    _fields_ = [("params", Params), ("segments", C.POINTER(C.c_double)), ("padded", C.POINTER(C.c_double)),
+                ("bodies", C.POINTER(Body)), ("n_segments", C.c_int32), ("n_bodies", C.c_int32)]
+
+
 class Stats(C.Structure):
     _fields_ = [("particles", C.c_int64), ("neighbor_slots", C.c_int64), ("max_neighbors", C.c_int32),
                 ("wall_particles", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32)]
@@ -68,6 +73,7 @@ SIGNATURES = {
     "sc_set_noise_host": (C.c_int, [_P, _D, C.c_int64]),
     "sc_step_finish": (C.c_int, [_P]),
     "sc_step": (C.c_int, [_P, C.c_int32]),
+    "sc_tick": (C.c_int, [_P, C.POINTER(TickInputs), C.POINTER(TickInputs)]),
     "sc_synchronize": (C.c_int, [_P]),
     "sc_download_sort": (C.c_int, [_P, _I64, _I64, C.c_int64, _I64]),
     "sc_download_neighbors": (C.c_int, [_P, _I64, _I32, _I64, _D, C.c_int64, _I64]),

@@ -46,6 +46,26 @@ _TICK_COEFFICIENTS = ("dt", "particle_radius", "wall_collision_decay", "pressure
                       "collider_noise_level", "viscosity", "surface_smoothing", "target_pressure")
 
 
+def tick_geometry(rigid_bodies, particle_radius, cache):
+    """-> (segments S x 2 x 2, padded 2S x 2 x 2, [(position, center_velocity, omega, n_segments)]) of one
+    tick: `Crate.segments` (crate.py:69-71) and `pad_segments` of it (geometry_utils.py:146-172).  Padding
+    is per segment, so bodies that did not move reuse their padded halves from `cache`."""
+    if not rigid_bodies:
+        return np.zeros((0, 2, 2)), np.zeros((0, 2, 2)), []
+    plus, minus = [], []
+    for body in rigid_bodies:
+        hit = cache.get(id(body))
+        if hit is None or hit[0] != particle_radius or not np.array_equal(hit[1], body.segments):
+            pad = pad_segments(body.segments, particle_radius)
+            hit = (particle_radius, body.segments.copy(), pad[: len(body)], pad[len(body):])
+            cache[id(body)] = hit
+        plus.append(hit[2])
+        minus.append(hit[3])
+    seg = np.vstack([body.segments for body in rigid_bodies])
+    bodies = [(b.position, b.center_velocity, b.angular_clockwise_velocity, len(b)) for b in rigid_bodies]
+    return seg, np.concatenate(plus + minus), bodies
+
+
 class Crate:
     def __init__(self, world_config: WorldConfig, *, device: int = 0, noise: str = "host", noise_seed: int = 0,
                  capacity: int | None = None) -> None:
@@ -72,6 +92,7 @@ class Crate:
         self._cache = None         # (particles, velocities, pressure) downloaded for this tick
         self._empty()
         self._tick_seconds = 0.0   # EMA of wall time per tick, for debug_prints
+        self._pad_cache = {}
         self.last_stats = None
 
     # ------------------------------------------------------------------ reference accessors
@@ -185,25 +206,21 @@ class Crate:
         if any(src.active_ticks > self.tick for src in self.particle_sources):
             raise RuntimeError("Crate.run cannot interleave particle sources; use physics_tick()")
         eng = self._engine
+        # One library call per tick (sc_tick).  Nobody can edit coefficients inside run(), so every tick
+        # also promises the next tick's inputs and its removal / wall pass rides on this tick's force
+        # kernel (sc_set_next_inputs); each tick's inputs are computed and packed once.
+        for body in self.rigid_bodies:
+            body.apply_velocity(self.dt)
+        now = self._pack_tick_inputs()
         for k in range(n_ticks):
-            if k == 0:
-                for body in self.rigid_bodies:
-                    body.apply_velocity(self.dt)
-            self._send_tick_inputs()
-            eng.step_begin()
+            nxt = None
             if k + 1 < n_ticks:
-                # nobody can edit coefficients inside run(): promise the next tick's inputs, so that its
-                # removal / wall pass rides on this tick's force kernel (sc_set_next_inputs)
                 for body in self.rigid_bodies:
                     body.apply_velocity(self.dt)
-                coef = {name: getattr(self, name) for name in _TICK_COEFFICIENTS}
-                bodies = self.rigid_bodies
-                seg = self.segments if bodies else np.zeros((0, 2, 2))
-                eng.set_next_inputs(gravity=self.gravity, segments=seg,
-                                    bodies=[(b.position, b.center_velocity, b.angular_clockwise_velocity, len(b))
-                                            for b in bodies], **coef)
-            eng.step_finish()
+                nxt = self._pack_tick_inputs()
+            eng.tick(now, nxt)
             self.tick += 1
+            now = nxt
         self._cache = None
         self._count_known = False
 
@@ -222,6 +239,11 @@ class Crate:
                 self._engine.append(new_p, new_v)
                 self._count += len(new_p)
                 self._cache = None
+
+    def _pack_tick_inputs(self):
+        coef = {name: getattr(self, name) for name in _TICK_COEFFICIENTS}
+        seg, pad, bodies = tick_geometry(self.rigid_bodies, self.particle_radius, self._pad_cache)
+        return self._engine.pack_inputs(coef, self.gravity, seg, pad, bodies)
 
     def _send_tick_inputs(self) -> None:
         coef = {name: getattr(self, name) for name in _TICK_COEFFICIENTS}

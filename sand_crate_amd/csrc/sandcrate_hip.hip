@@ -82,9 +82,11 @@ struct sc_ctx {
   int* tileBounds = nullptr;
   int *cellCount = nullptr, *cellStart = nullptr, *blockSums = nullptr, *blockOff = nullptr, *sortedStamp = nullptr;
   int* bigList = nullptr;
+  double *haloL = nullptr, *haloR = nullptr;  // send buffers of the last sc_halo_pack (caller-owned device memory)
+  int haloCap = 0;
   int* rankAcc = nullptr;  // per bucket slot: rank inside a big bucket (k_rank_big adds, k_reorder takes and clears)
   // host-mapped progress block written by the GPU, read by the host without synchronisation:
-  // [0] big buckets seen by the last finished scan, [1] ticks finished
+  // [0] big buckets seen by the last finished scan, [1] ticks finished, [2] live particles of that tick
   int* bigHintHost = nullptr;
   int* bigHintDev = nullptr;
   bool force_rank_big = false;
@@ -408,7 +410,10 @@ void launch_pass_a(sc_ctx* c, int kernel_id) {
   Bracket br(c, kernel_id);
   // up to 8 workgroups per CU: all resident with the wide tile too; beyond that the narrow tile's
   // higher occupancy wins (262,144 particles: 35.9 -> 32.2 us wide; 1,048,576: 78 us narrow, 82 us wide)
-  if (c->tile_choice ? c->tile_choice == 2 : tile_grid(c) <= 8 * c->num_cus)
+  // (slabs size their grids by capacity; the live count a recent tick published is the better estimate of the work)
+  const int published = *(volatile int*)(c->bigHintHost + 2);
+  const int tiles = c->slab && published > 0 ? (published + kTileW - 1) / kTileW + 64 : tile_grid(c);
+  if (c->tile_choice ? c->tile_choice == 2 : tiles <= 8 * c->num_cus)
     launch_pass_a_cap<NOISE, ENUM, DENS, kTileCapAWide>(c);
   else
     launch_pass_a_cap<NOISE, ENUM, DENS, kTileCapA>(c);
@@ -422,7 +427,7 @@ void launch_pass_b(sc_ctx* c, const WallInputs& wn) {
                      c->y[1], c->vx[1], c->vy[1], c->id[1], c->wslotT, c->cellT, c->nbr, c->cnt, (int)c->cap, c->eta,
                      c->offById, c->P, c->sx, c->sy, c->wrec[cur], c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0],
                      c->tileBounds, c->bigHintDev, wrec_counter_of(c->tick), wn, c->cellS, c->wslotS, c->cellCount,
-                     c->wrec[nxt], wrec_counter_of(c->tick + 1));
+                     c->wrec[nxt], wrec_counter_of(c->tick + 1), c->haloL, c->haloR, c->haloCap);
 }
 
 template <int NOISE>
@@ -475,9 +480,9 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
   if (e == hipSuccess) e = dalloc(&c->bigList, (size_t)kMaxBig);
   if (e == hipSuccess) e = dalloc(&c->rankAcc, n);
   if (e == hipSuccess) e = hipMemsetAsync(c->rankAcc, 0, n * sizeof(int), c->stream);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&c->bigHintHost, 2 * sizeof(int), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->bigHintHost, 4 * sizeof(int), hipHostMallocMapped);
   if (e == hipSuccess) {
-    c->bigHintHost[0] = c->bigHintHost[1] = 0;
+    c->bigHintHost[0] = c->bigHintHost[1] = c->bigHintHost[2] = c->bigHintHost[3] = 0;
     e = hipHostGetDevicePointer((void**)&c->bigHintDev, c->bigHintHost, 0);
   }
   if (e == hipSuccess) e = dalloc(&c->wrec[0], 5 * n);
@@ -737,11 +742,12 @@ int sc_step_finish(sc_ctx* c) {
   if (!c->in_step) return fail(SC_ERR_STATE, "sc_step_finish needs sc_step_begin first");
   if (c->noise_mode == SC_NOISE_HOST && c->etaPairs < 0)
     return fail(SC_ERR_STATE, "SC_NOISE_HOST: sc_set_noise_host must be called every tick");
-  // look-ahead: run K1 of the next tick in pass B's epilogue (not for slabs: the halo exchange adds
-  // particles between the ticks)
+  // look-ahead: run K1 of the next tick in pass B's epilogue.  Slabs: pass B also packs the next halo
+  // message into the buffers of the last sc_halo_pack, and sc_halo_unpack does K1 for what it appends.
   WallInputs wn;
   std::memset(&wn, 0, sizeof wn);
-  const bool fused = c->have_next && !c->slab && !c->custom_grid;
+  const bool slab_ready = !c->slab || c->haloL || !(c->has_left || c->has_right);
+  const bool fused = c->have_next && slab_ready && !c->custom_grid;
   if (fused) {
     World next;
     int rc = build_world(c, next, c->next_params, c->next_nseg, c->next_seg, nullptr, c->next_nbody, c->next_body,
@@ -795,6 +801,26 @@ int sc_step(sc_ctx* c, int32_t n_ticks) {
     if (rc) return rc;
   }
   return SC_OK;
+}
+
+int sc_tick(sc_ctx* c, const sc_tick_inputs* now, const sc_tick_inputs* next) {
+  if (!c || !now) return fail(SC_ERR_ARG, "null argument");
+  if (c->noise_mode == SC_NOISE_HOST) return fail(SC_ERR_STATE, "sc_tick is not available in SC_NOISE_HOST mode");
+  int rc = sc_set_params(c, &now->params);
+  if (rc) return rc;
+  rc = sc_set_segments(c, now->segments, now->padded, now->n_segments, now->bodies, now->n_bodies);
+  if (rc) return rc;
+  rc = sc_step_begin(c);
+  if (rc) return rc;
+  if (next) {
+    rc = sc_set_next_inputs(c, &next->params, next->segments, next->n_segments, next->bodies, next->n_bodies);
+    if (rc) {
+      c->have_next = false;
+      (void)sc_step_finish(c);  // leave the context between ticks; the error of the promise is what is reported
+      return rc;
+    }
+  }
+  return sc_step_finish(c);
 }
 
 int sc_set_next_inputs(sc_ctx* c, const sc_params* p, const double* segments, int32_t ns, const sc_body* bodies,
@@ -1080,9 +1106,13 @@ int sc_halo_pack(sc_ctx* c, double* dev_left, double* dev_right, int64_t cap_rec
   if (c->in_step) return fail(SC_ERR_STATE, "halo exchange happens between ticks");
   int rc = make_world(c);
   if (rc) return rc;
+  if (c->prebinned) return fail(SC_ERR_STATE, "the halo message of the promised tick was packed by sc_step_finish");
+  c->haloL = dev_left;  // stay bound: with sc_set_next_inputs, sc_step_finish packs the next message itself
+  c->haloR = dev_right;
+  c->haloCap = (int)cap_records;
   Bracket br(c, K_HALO_PACK);
   hipLaunchKernelGGL(k_halo_pack, dim3(grid_for(launch_bound(c))), dim3(kBlock), 0, c->stream, c->w, c->counters, c->x[0],
-                     c->y[0], c->vx[0], c->vy[0], c->id[0], dev_left, dev_right, (int)cap_records);
+                     c->y[0], c->vx[0], c->vy[0], c->id[0], dev_left, dev_right, (int)cap_records, (int)c->cap);
   HIPCHK(hipGetLastError());
   return SC_OK;
 }
@@ -1092,8 +1122,18 @@ int sc_halo_unpack(sc_ctx* c, const double* from_left, const double* from_right,
   if (!c->slab) return fail(SC_ERR_STATE, "sc_set_slab first");
   if (c->in_step) return fail(SC_ERR_STATE, "halo exchange happens between ticks");
   Bracket br(c, K_HALO_UNPACK);
-  hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(2 * cap_records)), dim3(kBlock), 0, c->stream, from_left, from_right,
-                     (int)cap_records, c->counters, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], (int)c->cap);
+  const dim3 grid(grid_for(2 * cap_records)), block(kBlock);
+  if (c->prebinned) {  // the stored particles went through K1 of the coming tick in pass B: same for the arrivals
+    hipLaunchKernelGGL(k_halo_unpack<true>, grid, block, 0, c->stream, from_left, from_right, (int)cap_records,
+                       c->counters, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], (int)c->cap, c->haloL, c->haloR,
+                       c->promised, c->cellS, c->wslotS, c->cellCount, c->wrec[c->tick & 1], wrec_counter_of(c->tick));
+  } else {
+    WallInputs none;
+    std::memset(&none, 0, sizeof none);
+    hipLaunchKernelGGL(k_halo_unpack<false>, grid, block, 0, c->stream, from_left, from_right, (int)cap_records,
+                       c->counters, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], (int)c->cap, c->haloL, c->haloR, none,
+                       c->cellS, c->wslotS, c->cellCount, c->wrec[c->tick & 1], wrec_counter_of(c->tick));
+  }
   HIPCHK(hipGetLastError());
   return SC_OK;
 }

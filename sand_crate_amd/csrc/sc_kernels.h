@@ -618,83 +618,108 @@ __device__ __forceinline__ void collider_noise(const World& w, uint64_t z, int s
 
 // ------------------------------------------------------------------------------------------
 // Halo exchange for x-slabs (no reference counterpart).  Records are
-// (x, y, vx, vy, id) as five doubles; record 0 of a buffer is a header whose first field is the
-// record count, so one fixed-size message per direction carries everything and the host never
-// needs to know the count.
-//   k_halo_pack   every stored particle within `halo` columns of a slab edge -- including those
-//                 that already left the slab on that side (migrants) -- goes to that neighbor; the
-//                 last workgroup to finish publishes the counts and re-arms the counters.
-//   k_halo_unpack appends the received buffers to the storage arrays; whether a record is owned or
-//                 a ghost here is decided by its column in K1, not by the sender.
-// Two launches per tick in all: each tiny launch costs ~4 us at this problem size.
+// (x, y, vx, vy, id) as five doubles; record 0 of a buffer is a header whose first 32-bit word is the
+// record count -- the very counter the packing kernel increments, so one fixed-size message per
+// direction carries everything, nothing has to be published after the last record, and the host
+// never needs to know the count.  The receiver's unpack re-arms the local send headers (in stream
+// order the sends are over by then).
+//   halo_pack_one  a particle within `halo` columns of a slab edge -- or already beyond it (a migrant) --
+//                  goes to that neighbor; one atomic per wave and direction.  Called from k_halo_pack
+//                  and, when the next tick's inputs are promised, from pass B's epilogue, so that the
+//                  steady-state tick has no packing launch.
+//   k_halo_unpack  appends the received buffers to the storage arrays; whether a record is owned or
+//                  a ghost here is decided by its column in K1, not by the sender.  FUSED: K1 of the
+//                  coming tick for the appended particles as well (pass B did it for the stored ones).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
-    k_halo_pack(World w, int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
-                const double* __restrict__ vx, const double* __restrict__ vy, const int* __restrict__ id,
-                double* __restrict__ left, double* __restrict__ right, int cap) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < counters[C_NS]) {
-    double px = x[i];
-    if (fabs(px) < 1e300) {  // not a dead ghost copy (x = +inf)
-      long long col = (long long)floor(px / w.d);
-      bool toL = w.has_left && col < w.own_lo + w.halo;
-      bool toR = w.has_right && col >= w.own_hi - w.halo;
-      if (toL || toR) {
-        double py = y[i], pvx = vx[i], pvy = vy[i], pid = (double)id[i];
-        if (toL) {
-          int k = atomicAdd(&counters[C_PACK_L], 1);
-          if (k < cap) {
-            double* r = left + (size_t)kHaloFields * (k + 1);
-            r[0] = px; r[1] = py; r[2] = pvx; r[3] = pvy; r[4] = pid;
-          }
-        }
-        if (toR) {
-          int k = atomicAdd(&counters[C_PACK_R], 1);
-          if (k < cap) {
-            double* r = right + (size_t)kHaloFields * (k + 1);
-            r[0] = px; r[1] = py; r[2] = pvx; r[3] = pvy; r[4] = pid;
-          }
-        }
-      }
-    }
+// every lane of the wave calls this; lanes that `want` get a record index in `buf`
+__device__ __forceinline__ int halo_slot(bool want, double* __restrict__ buf) {
+  const unsigned long long m = __ballot(want);
+  if (!m) return -1;
+  const int lane = threadIdx.x & 63, leader = __ffsll(m) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(reinterpret_cast<int*>(buf), (int)__popcll(m));
+  base = __shfl(base, leader, 64);
+  return want ? base + (int)__popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+
+// `d`, own_lo .. has_right: the slab of the COMING tick.  `on`: this lane holds a stored, live particle.
+__device__ __forceinline__ void halo_pack_one(bool on, double px, double py, double pvx, double pvy, int pid, double d,
+                                              long long own_lo, long long own_hi, int halo, int has_left,
+                                              int has_right, double* __restrict__ left, double* __restrict__ right,
+                                              int cap, int* __restrict__ counters) {
+  bool toL = false, toR = false;
+  if (on && fabs(px) < 1e300) {  // not a dead ghost copy (x = +inf), not NaN
+    const long long col = (long long)floor(px / d);
+    toL = has_left && col < own_lo + halo;
+    toR = has_right && col >= own_hi - halo;
   }
-  // The last workgroup to get here publishes the two counts as record 0 of each buffer and re-arms
-  // the counters.  Device-scope atomics order the ticket against every workgroup's record counts;
-  // the records themselves are only read by later kernels / the NIC after the kernel boundary.
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    if (atomicAdd(&counters[C_TICKET], 1) == (int)gridDim.x - 1) {
-      int nl = atomicExch(&counters[C_PACK_L], 0), nr = atomicExch(&counters[C_PACK_R], 0);
-      if (nl > cap || nr > cap) atomicOr(&counters[C_FLAGS], F_HALO_OVERFLOW);
-      left[0] = (double)min(nl, cap);
-      right[0] = (double)min(nr, cap);
-      counters[C_TICKET] = 0;
-    }
+  const int kl = halo_slot(toL, left), kr = halo_slot(toR, right);
+  if (kl >= cap || kr >= cap) atomicOr(&counters[C_FLAGS], F_HALO_OVERFLOW);
+  if (kl >= 0 && kl < cap) {
+    double* r = left + (size_t)kHaloFields * (kl + 1);
+    r[0] = px; r[1] = py; r[2] = pvx; r[3] = pvy; r[4] = (double)pid;
+  }
+  if (kr >= 0 && kr < cap) {
+    double* r = right + (size_t)kHaloFields * (kr + 1);
+    r[0] = px; r[1] = py; r[2] = pvx; r[3] = pvy; r[4] = (double)pid;
   }
 }
 
-// Appends the received buffers (either may be null) to the storage arrays.  Every workgroup reads
-// the old stored count first; the last one to finish adds the two record counts to it.
+__global__ void __launch_bounds__(kBlock)
+    k_halo_pack(World w, int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
+                const double* __restrict__ vx, const double* __restrict__ vy, const int* __restrict__ id,
+                double* __restrict__ left, double* __restrict__ right, int cap, int capS) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ic = min(i, capS - 1);
+  const bool on = i < counters[C_NS];
+  halo_pack_one(on, x[ic], y[ic], vx[ic], vy[ic], id[ic], w.d, w.own_lo, w.own_hi, w.halo, w.has_left, w.has_right, left,
+                right, cap, counters);
+}
+
+// Appends the received buffers (either may be null) to the storage arrays and re-arms the local
+// send headers.  Plain: every workgroup reads the old stored count first, the last one to finish
+// (ticket) adds the two record counts to it.  FUSED (pass B of the previous tick ran K1 for the stored
+// particles): the stored count is the sorted count of that tick, nobody changes it, and the appended
+// particles get their K1 here.
+template <bool FUSED>
 __global__ void __launch_bounds__(kBlock)
     k_halo_unpack(const double* __restrict__ bufL, const double* __restrict__ bufR, int cap, int* __restrict__ counters,
                   double* __restrict__ x, double* __restrict__ y, double* __restrict__ vx, double* __restrict__ vy,
-                  int* __restrict__ id, int capS) {
-  const int nl = bufL ? min((int)bufL[0], cap) : 0;
-  const int nr = bufR ? min((int)bufR[0], cap) : 0;
-  const int base = __hip_atomic_load(&counters[C_NS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  int* __restrict__ id, int capS, double* __restrict__ sendL, double* __restrict__ sendR, WallInputs wn,
+                  int* __restrict__ cellS, int* __restrict__ wslotS, int* __restrict__ cellCount,
+                  double* __restrict__ wrec_next, int wrec_counter_next) {
+  const int nl = bufL ? min(*reinterpret_cast<const int*>(bufL), cap) : 0;
+  const int nr = bufR ? min(*reinterpret_cast<const int*>(bufR), cap) : 0;
+  const int base = FUSED ? counters[C_NT] : __hip_atomic_load(&counters[C_NS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  int cnext = -1;
   if (k < nl + nr) {
     const double* r = k < nl ? bufL + (size_t)kHaloFields * (k + 1) : bufR + (size_t)kHaloFields * (k - nl + 1);
     if (base + k >= capS) {
       atomicOr(&counters[C_FLAGS], F_CAPACITY);
     } else {
-      x[base + k] = r[0];
-      y[base + k] = r[1];
+      double px = r[0], py = r[1];
+      if (FUSED) {
+        int wsn = -1;
+        cnext = wall_and_cell(wn, px, py, wsn, counters, wrec_counter_next, wrec_next);
+        cellS[base + k] = cnext;
+        if (cnext >= 0) wslotS[base + k] = wsn;
+      }
+      x[base + k] = px;
+      y[base + k] = py;
       vx[base + k] = r[2];
       vy[base + k] = r[3];
       id[base + k] = (int)r[4];
     }
+  }
+  if (FUSED) {
+    count_cells(cnext, cellCount);  // every lane of the wave takes part
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      counters[C_NS] = min(base + nl + nr, capS);
+      if (sendL) *reinterpret_cast<int*>(sendL) = 0;
+      if (sendR) *reinterpret_cast<int*>(sendR) = 0;
+    }
+    return;
   }
   __syncthreads();  // every thread of this workgroup has read `base`
   if (threadIdx.x == 0) {
@@ -702,6 +727,8 @@ __global__ void __launch_bounds__(kBlock)
     if (atomicAdd(&counters[C_TICKET], 1) == (int)gridDim.x - 1) {
       counters[C_NS] = min(base + nl + nr, capS);
       counters[C_TICKET] = 0;
+      if (sendL) *reinterpret_cast<int*>(sendL) = 0;
+      if (sendR) *reinterpret_cast<int*>(sendR) = 0;
     }
   }
 }

@@ -563,7 +563,8 @@ __global__ void __launch_bounds__(kTileW)
              double* __restrict__ yo, double* __restrict__ vxo, double* __restrict__ vyo, int* __restrict__ ido,
              const int* __restrict__ tileBounds, volatile int* __restrict__ progress, int wrec_counter,
              WallInputs wn, int* __restrict__ cellS, int* __restrict__ wslotS, int* __restrict__ cellCount,
-             double* __restrict__ wrec_next, int wrec_counter_next) {
+             double* __restrict__ wrec_next, int wrec_counter_next, double* __restrict__ haloL,
+             double* __restrict__ haloR, int haloCap) {
   __shared__ Rec tile[kTileCapB];
 
   const int t = threadIdx.x;
@@ -591,6 +592,7 @@ __global__ void __launch_bounds__(kTileW)
     counters[C_MAXC] = 0;
     counters[C_NBIG] = 0;
     progress[1] = w.tick + 1;  // host-mapped: the host keeps at most a few ticks of launches queued
+    progress[2] = n;           // ... and sizes heuristics by a recent live count
   }
   if (i0 >= n) return;
   const int m = min(kTileW, n - i0);
@@ -647,12 +649,18 @@ __global__ void __launch_bounds__(kTileW)
   }
   if (FUSED) {
     int cnext = -1, wsn = -1;
+    const double xp = xn, yp = yn;  // as integrated: what a halo message carries (the receiver runs its own K1)
     if (active) cnext = wall_and_cell(wn, xn, yn, wsn, counters, wrec_counter_next, wrec_next);
     if (live) {
       cellS[i] = cnext;
       if (cnext >= 0) wslotS[i] = wsn;
     }
     count_cells(cnext, cellCount);  // every lane of the wave takes part
+    // slabs: the coming tick's halo message is packed here too (same rule and same pre-wall-fix position as
+    // k_halo_pack); a workgroup-uniform branch, every lane of the wave takes part
+    if (wn.slab && haloL)
+      halo_pack_one(active, xp, yp, vxn, vyn, idn, wn.d, w.own_lo, w.own_hi, w.halo, w.has_left, w.has_right, haloL,
+                    haloR, haloCap, counters);
   }
   if (live) {
     xo[i] = xn;

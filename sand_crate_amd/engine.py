@@ -23,6 +23,34 @@ class StepStats:
     flags: int
 
 
+_COEF_ORDER = ("dt", "particle_radius", "wall_collision_decay", "pressure_amplifier", "ignored_pressure",
+               "collider_noise_level", "viscosity", "surface_smoothing", "target_pressure")
+
+
+class PackedInputs:
+    """sc_tick_inputs plus the NumPy buffers it points into (kept alive with it)."""
+
+    __slots__ = ("struct", "ref", "_seg", "_pad", "_bodies")
+
+    def __init__(self, coef, gravity, segments, padded, bodies):
+        seg = N.f64(segments).reshape(-1, 2, 2)
+        pad = N.f64(padded).reshape(-1, 2, 2)
+        if len(pad) != 2 * len(seg):
+            raise ValueError("padded must hold two segments per wall segment")
+        bodies = list(bodies)
+        arr = (N.Body * max(len(bodies), 1))()
+        for k, (pos, vel, omega, nseg) in enumerate(bodies):
+            arr[k] = N.Body(float(pos[0]), float(pos[1]), float(vel[0]), float(vel[1]), float(omega), int(nseg), 0)
+        t = N.TickInputs()
+        t.params = N.Params(*(float(coef[k]) for k in _COEF_ORDER), float(gravity[0]), float(gravity[1]))
+        t.segments = N.dptr(seg)
+        t.padded = N.dptr(pad)
+        t.bodies = arr
+        t.n_segments = len(seg)
+        t.n_bodies = len(bodies)
+        self.struct, self.ref, self._seg, self._pad, self._bodies = t, C.byref(t), seg, pad, arr
+
+
 class Engine:
     def __init__(self, capacity: int, device: int = 0):
         self._lib = N.load()
@@ -123,6 +151,15 @@ class Engine:
             vel = np.asarray(vel, dtype=np.float64).reshape(2)
             arr[k] = N.Body(pos[0], pos[1], vel[0], vel[1], float(omega), int(nseg), 0)
         N.check(self._lib.sc_set_next_inputs(self._ctx, C.byref(p), N.dptr(seg), len(seg), arr, len(bodies)))
+
+    def pack_inputs(self, coef, gravity, segments, padded, bodies) -> "PackedInputs":
+        """The inputs of one tick as one C struct (sc_tick_inputs): `coef` maps the nine per-tick coefficient
+        names to values, `bodies` is an iterable of (position, center_velocity, omega, n_segments)."""
+        return PackedInputs(coef, gravity, segments, padded, bodies)
+
+    def tick(self, now: "PackedInputs", nxt: "PackedInputs | None" = None) -> None:
+        """One whole tick in one library call (sc_tick); `nxt` promises the next tick's inputs."""
+        N.check(self._lib.sc_tick(self._ctx, now.ref, nxt.ref if nxt is not None else None))
 
     def set_noise_mode(self, mode: int, seed: int = 0) -> None:
         N.check(self._lib.sc_set_noise_mode(self._ctx, int(mode), int(seed) & (2 ** 64 - 1)))

@@ -29,9 +29,8 @@ import math
 
 import numpy as np
 
-from .crate import _NOISE_MODES, _TICK_COEFFICIENTS
+from .crate import _NOISE_MODES, _TICK_COEFFICIENTS, tick_geometry
 from .rigid_body import build_rigid_bodies
-from .utils.geometry_utils import pad_segments
 
 HALO_COLUMNS = 3
 HALO_FIELDS = 5
@@ -89,6 +88,9 @@ class HipSlabBackend:
         self.recv_left = torch.zeros(shape, dtype=torch.float64, device=self.device)
         self.recv_right = torch.zeros(shape, dtype=torch.float64, device=self.device)
         self._N = N
+        self._params_key = None
+        self._inputs = None
+        self.packed_ahead = False
 
     def load(self, particles, velocities, ids) -> None:
         self.engine.upload_with_ids(particles, velocities, ids)
@@ -97,8 +99,11 @@ class HipSlabBackend:
         self.engine.set_slab(lo, hi, halo, has_left, has_right)
 
     def set_tick_inputs(self, coef, gravity, segments, padded, bodies) -> None:
-        self.engine.set_params(gravity=gravity, **coef)
-        self.engine.set_segments(segments, padded, bodies)
+        self._inputs = self.engine.pack_inputs(coef, gravity, segments, padded, bodies)
+        key = (tuple(coef.values()), float(gravity[0]), float(gravity[1]))
+        if key != self._params_key:  # the halo kernels need the grid (diameter) before the tick itself runs
+            self.engine.set_params(gravity=gravity, **coef)
+            self._params_key = key
 
     def pack(self) -> None:
         self.engine.halo_pack(self.send_left.data_ptr(), self.send_right.data_ptr(), self.halo_capacity)
@@ -107,8 +112,12 @@ class HipSlabBackend:
         self.engine.halo_unpack(self.recv_left.data_ptr() if from_left else None,
                                 self.recv_right.data_ptr() if from_right else None, self.halo_capacity)
 
-    def step(self) -> None:
-        self.engine.step(1)
+    def step(self, next_inputs=None) -> None:
+        """The tick, one library call.  With the next tick's inputs promised, the force kernel also runs that
+        tick's removal / wall pass and packs its halo message into the send buffers (sc_set_next_inputs)."""
+        nxt = self.engine.pack_inputs(*next_inputs) if next_inputs is not None else None
+        self.engine.tick(self._inputs, nxt)
+        self.packed_ahead = nxt is not None
 
     def synchronize(self) -> None:
         self.engine.synchronize()
@@ -142,6 +151,7 @@ class SlabCrate:
             setattr(self, name, value)
         self.gravity = np.array(world_config.coefficients["gravity"], dtype=np.float64)
         self.tick = 0
+        self._pad_cache = {}
 
         p = np.ascontiguousarray(particles, dtype=np.float64).reshape(-1, 2)
         v = np.ascontiguousarray(velocities, dtype=np.float64).reshape(-1, 2)
@@ -175,10 +185,8 @@ class SlabCrate:
 
     def _tick_inputs(self):
         coef = {name: getattr(self, name) for name in _TICK_COEFFICIENTS}
-        seg = np.vstack([b.segments for b in self.rigid_bodies]) if self.rigid_bodies else np.zeros((0, 2, 2))
-        pad = pad_segments(seg, self.particle_radius) if len(seg) else np.zeros((0, 2, 2))
-        bodies = [(b.position, b.center_velocity, b.angular_clockwise_velocity, len(b)) for b in self.rigid_bodies]
-        return coef, seg, pad, bodies
+        seg, pad, bodies = tick_geometry(self.rigid_bodies, self.particle_radius, self._pad_cache)
+        return coef, np.array(self.gravity, dtype=np.float64), seg, pad, bodies
 
     def _exchange(self) -> None:
         """One message each way with each existing neighbor."""
@@ -216,17 +224,28 @@ class SlabCrate:
 
     def run(self, n_ticks: int) -> None:
         be = self.backend
-        for _ in range(n_ticks):
-            for body in self.rigid_bodies:
-                body.apply_velocity(self.dt)
-            coef, seg, pad, bodies = self._tick_inputs()
-            be.set_tick_inputs(coef, self.gravity, seg, pad, bodies)
+        now = None
+        for k in range(n_ticks):
+            if now is None:
+                for body in self.rigid_bodies:
+                    body.apply_velocity(self.dt)
+                now = self._tick_inputs()
+            be.set_tick_inputs(*now)
             if self.world > 1:
-                be.pack()
+                # a backend that was promised this tick's inputs packed its halo message at the end of the
+                # previous tick (HipSlabBackend: in the force kernel's epilogue)
+                if not getattr(be, "packed_ahead", False):
+                    be.pack()
                 self._exchange()
                 be.unpack(self.left is not None, self.right is not None)
-            be.step()
+            nxt = None
+            if k + 1 < n_ticks:  # nobody can edit coefficients inside run(): the next tick's inputs are known
+                for body in self.rigid_bodies:
+                    body.apply_velocity(self.dt)
+                nxt = self._tick_inputs()
+            be.step(nxt)
             self.tick += 1
+            now = nxt
 
     def physics_tick(self) -> None:
         self.run(1)

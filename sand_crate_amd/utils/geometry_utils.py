@@ -20,12 +20,20 @@ def pad_segments(segments: np.ndarray, pad_distance: float) -> np.ndarray:
     """Two parallel copies of every segment at +-pad_distance: first all (a+o, b+o), then all
     (b-o, a-o), with o = cw90(b - a) * pad_distance / |b - a|."""
     segments = np.asarray(segments, dtype=np.float64)
+    n = len(segments)
     start, end = segments[:, 0, :], segments[:, 1, :]
-    normal = rotate_vectors_clockwise_90_deg(end - start)
-    offset = normal * pad_distance / np.linalg.norm(normal, axis=1)[:, None]
-    plus = np.stack((start + offset, end + offset), axis=1)
-    minus = np.stack((end - offset, start - offset), axis=1)
-    return np.concatenate((plus, minus), axis=0)
+    along = end - start
+    nx, ny = along[:, 1], -along[:, 0]            # clockwise quarter turn of (end - start)
+    norm = np.sqrt(nx * nx + ny * ny)             # = np.linalg.norm(normal, axis=1) for two components
+    ox, oy = nx * pad_distance / norm, ny * pad_distance / norm
+    out = np.empty((2 * n, 2, 2))
+    out[:n, :, 0] = segments[:, :, 0] + ox[:, None]
+    out[:n, :, 1] = segments[:, :, 1] + oy[:, None]
+    out[n:, 0, 0] = end[:, 0] - ox
+    out[n:, 0, 1] = end[:, 1] - oy
+    out[n:, 1, 0] = start[:, 0] - ox
+    out[n:, 1, 1] = start[:, 1] - oy
+    return out
 
 
 def points_to_segments_distance(p, segments, device: int = 0):

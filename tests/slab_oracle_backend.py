@@ -58,7 +58,7 @@ class OracleSlabBackend:
             self.v = np.vstack((self.v, rec[:, 2:4]))
             self.ids = np.concatenate((self.ids, rec[:, 4].astype(np.int64)))
 
-    def step(self):
+    def step(self, next_inputs=None):  # no look-ahead here: SlabCrate packs explicitly every tick
         c = self.coef
         p, v, ids = remove_outside(self.p, self.v, c["particle_radius"], self.ids)
         col = column_of(p[:, 0], 2 * c["particle_radius"])

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--vel", type=float, default=30.0)
     ap.add_argument("--noise", default="counter")
     ap.add_argument("--margin", type=float, default=0.0)
+    ap.add_argument("--mixed", action="store_true", help="run(2), physics_tick(), run(rest): look-ahead on and off")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     import torch.distributed as dist
@@ -45,7 +46,12 @@ def main():
         from slab_oracle_backend import OracleSlabBackend
         backend = OracleSlabBackend(halo_capacity=a.particles, noise=a.noise, noise_seed=9)
     sim = SlabCrate(wc, p, v, device=0, noise=a.noise, noise_seed=9, backend=backend)
-    sim.run(a.ticks)
+    if a.mixed:
+        sim.run(2)
+        sim.physics_tick()
+        sim.run(a.ticks - 3)
+    else:
+        sim.run(a.ticks)
     sim.synchronize()
     count = sim.global_particle_count()
     gp, gv, gpr, gids = sim.gather_state()

@@ -58,3 +58,27 @@ def test_rigid_bodies_match_the_oracle_world():
             assert np.array_equal(a.segments, b.segments)
             assert np.array_equal(np.asarray(a.center_velocity, float), np.asarray(b.center_velocity, float))
             assert float(a.angular_clockwise_velocity) == float(b.angular_clockwise_velocity)
+
+
+def test_host_body_motion_and_tick_geometry_match_the_reference():
+    """rigid_body.py:42-68 + crate.py:69-71 + geometry_utils.py:146-172 on the host, no GPU: the moving walls
+    of both scenes at the golden ticks, bit for bit, and the padded set assembled from per-body halves
+    (fixed bodies cached) equal to padding the whole segment array."""
+    from sand_crate_amd.crate import tick_geometry
+    from sand_crate_amd.load_config import load_config
+    from sand_crate_amd.rigid_body import build_rigid_bodies
+    from sand_crate_amd.utils.geometry_utils import pad_segments
+    for scene in ("stirring_cup", "wave_machine"):
+        g = np.load(ROOT / "tests" / "golden" / f"traj_{scene}.npz")
+        wc = load_config(ROOT / "config" / f"{scene}.yaml").world_config
+        bodies = build_rigid_bodies(wc.rigid_bodies)
+        dt, r = wc.coefficients["dt"], wc.coefficients["particle_radius"]
+        cache = {}
+        for t in range(1, int(g["ticks"].max()) + 1):
+            for b in bodies:
+                b.apply_velocity(dt)
+            seg, pad, packed = tick_geometry(bodies, r, cache)
+            if t in g["ticks"]:
+                assert np.array_equal(seg, g[f"segments_t{t}"]), (scene, t)
+                assert np.array_equal(pad, pad_segments(seg, r))
+                assert [n for *_, n in packed] == [len(b) for b in bodies]

@@ -249,19 +249,21 @@ def test_particles_outside_are_removed(sc):
 
 
 # ------------------------------------------------------------------ multi-rank slabs on one GPU
-@pytest.mark.parametrize("nproc", [2, 3])
-def test_slabs_on_gpu_equal_single_gpu(sc, tmp_path, nproc):
+@pytest.mark.parametrize("nproc,mixed", [(2, False), (3, False), (2, True)])
+def test_slabs_on_gpu_equal_single_gpu(sc, tmp_path, nproc, mixed):
     """The HIP slab path (ownership by column, ghosts, halo pack/unpack, migration) with `nproc`
     gloo ranks sharing cuda:0 must reproduce the single-GPU run bit for bit: every owned particle
-    sees the same neighbor list, in the same order, with the same counter noise."""
+    sees the same neighbor list, in the same order, with the same counter noise.  Inside run() every tick
+    promises the next one's inputs, so the force kernel packs the halo message and the unpack kernel does the
+    wall pass of what it appends; `mixed` alternates that with unpromised ticks (explicit pack, k_wall_bin)."""
     import sys
     from pathlib import Path
     sys.path.insert(0, str(Path(__file__).resolve().parent))
     from slab_worker import synthetic_world
     from test_slab_gloo_cpu import run_workers
-    n, ticks, vel = 40000, 5, 30.0
+    n, ticks, vel = 40000, 6, 30.0
     got = run_workers(nproc, tmp_path / "slab.npz", "--backend", "hip", "--particles", str(n), "--ticks", str(ticks),
-                      "--vel", str(vel), "--noise", "counter")
+                      "--vel", str(vel), "--noise", "counter", *(["--mixed"] if mixed else []))
     wc, p, v = synthetic_world(n, 0.1, vel)
     crate = sc.Crate(wc, noise="counter", noise_seed=9, capacity=n + 1024)
     crate.particles = p
