@@ -214,6 +214,22 @@ int sc_set_slab(sc_ctx* ctx, int64_t col_lo, int64_t col_hi, int32_t halo, int32
 int sc_upload_state_ids(sc_ctx* ctx, const double* xy, const double* vxy, const int64_t* ids, int64_t n);
 int sc_halo_pack(sc_ctx* ctx, double* dev_left, double* dev_right, int64_t capacity_records);
 int sc_halo_unpack(sc_ctx* ctx, const double* dev_from_left, const double* dev_from_right, int64_t capacity_records);
+/* RCCL transport for the exchange step (optional: any transport that moves the buffers between the
+ * calls above will do; sand_crate_amd.slab falls back to torch.distributed P2P ops).  librccl is dlopen()ed
+ * on first use -- the copy already loaded in the process if any, else `rccl_path`, else the default search
+ * path -- so the library itself has no link-time dependency on it.
+ *   sc_comm_unique_id  rank 0: 128 bytes to hand to every rank (ncclGetUniqueId)
+ *   sc_comm_init       collective over the `world` contexts of the slab chain (ncclCommInitRank); rank = slab index
+ *   sc_halo_exchange   on the context's stream, one group: send `send_left` to / receive `recv_left` from
+ *                      rank `left_rank`, the same on the right; a negative rank means no neighbor on that side.
+ *                      All four buffers are (capacity_records + 1) * 5 doubles of device memory.
+ * A failing RCCL call returns SC_ERR_HIP with RCCL's message in sc_last_error(). */
+int sc_comm_unique_id(const char* rccl_path, void* id_128_bytes);
+int sc_comm_init(sc_ctx* ctx, const char* rccl_path, const void* id_128_bytes, int32_t rank, int32_t world);
+int sc_comm_destroy(sc_ctx* ctx);
+int sc_halo_exchange(sc_ctx* ctx, const double* send_left, double* recv_left, int32_t left_rank,
+                     const double* send_right, double* recv_right, int32_t right_rank, int64_t capacity_records);
+
 /* Synchronises.  Live particles stored in this context (dead ghost copies excluded); summed over
  * the ranks this is the global particle count. */
 int sc_owned_count(sc_ctx* ctx, int64_t* n);

@@ -18,7 +18,7 @@ LIB = PKG / "libsandcrate_hip.so"
 # -ffp-contract=off: float64 decisions must match NumPy's separately rounded multiply/add
 # ("hard parts"); the kernels spell out fma() where fusing is harmless.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-         f"-I{ROOT / 'include'}", f"-I{PKG / 'csrc'}"]
+         f"-I{ROOT / 'include'}", f"-I{PKG / 'csrc'}", "-ldl"]
 
 
 def hipcc() -> str:

@@ -18,6 +18,7 @@
 
 #include "sandcrate_hip.h"
 #include "sc_kernels.h"
+#include "sc_rccl.h"
 #include "sc_tiled.h"
 
 using namespace sc;
@@ -82,6 +83,8 @@ struct sc_ctx {
   int* tileBounds = nullptr;
   int *cellCount = nullptr, *cellStart = nullptr, *blockSums = nullptr, *blockOff = nullptr, *sortedStamp = nullptr;
   int* bigList = nullptr;
+  RcclComm comm = nullptr;  // RCCL communicator of the slab chain (sc_comm_init), or null
+  int comm_rank = -1, comm_world = 0;
   double *haloL = nullptr, *haloR = nullptr;  // send buffers of the last sc_halo_pack (caller-owned device memory)
   int haloCap = 0;
   int* rankAcc = nullptr;  // per bucket slot: rank inside a big bucket (k_rank_big adds, k_reorder takes and clears)
@@ -507,6 +510,7 @@ int sc_destroy(sc_ctx* c) {
   if (!c) return SC_OK;
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  if (c->comm) (void)sc_comm_destroy(c);
   for (int s = 0; s < 2; ++s) {
     (void)hipFree(c->x[s]);
     (void)hipFree(c->y[s]);
@@ -1135,6 +1139,74 @@ int sc_halo_unpack(sc_ctx* c, const double* from_left, const double* from_right,
                        c->cellS, c->wslotS, c->cellCount, c->wrec[c->tick & 1], wrec_counter_of(c->tick));
   }
   HIPCHK(hipGetLastError());
+  return SC_OK;
+}
+
+#define RCCLCHK(expr)                                                                       \
+  do {                                                                                      \
+    int rc_ = (expr);                                                                       \
+    if (rc_ != 0) return fail(SC_ERR_HIP, "RCCL: %s failed: %s", #expr, rccl_error(rc_)); \
+  } while (0)
+
+int sc_comm_unique_id(const char* rccl_path, void* id) {
+  if (!id) return fail(SC_ERR_ARG, "null argument");
+  if (rccl_load(rccl_path)) return fail(SC_ERR_HIP, "%s", rccl_api().error.c_str());
+  RcclUniqueId u;
+  RCCLCHK(rccl_api().GetUniqueId(&u));
+  std::memcpy(id, &u, sizeof u);
+  return SC_OK;
+}
+
+int sc_comm_init(sc_ctx* c, const char* rccl_path, const void* id, int32_t rank, int32_t world) {
+  if (!c || !id) return fail(SC_ERR_ARG, "null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(SC_ERR_ARG, "rank %d of %d", rank, world);
+  if (c->comm) return fail(SC_ERR_STATE, "sc_comm_init called twice");
+  if (rccl_load(rccl_path)) return fail(SC_ERR_HIP, "%s", rccl_api().error.c_str());
+  HIPCHK(hipSetDevice(c->device));
+  RcclUniqueId u;
+  std::memcpy(&u, id, sizeof u);
+  RCCLCHK(rccl_api().CommInitRank(&c->comm, world, u, rank));
+  c->comm_rank = rank;
+  c->comm_world = world;
+  return SC_OK;
+}
+
+int sc_comm_destroy(sc_ctx* c) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  if (!c->comm) return SC_OK;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  RcclComm comm = c->comm;
+  c->comm = nullptr;
+  RCCLCHK(rccl_api().CommDestroy(comm));
+  return SC_OK;
+}
+
+int sc_halo_exchange(sc_ctx* c, const double* send_left, double* recv_left, int32_t left_rank, const double* send_right,
+                     double* recv_right, int32_t right_rank, int64_t cap_records) {
+  if (!c || cap_records < 1) return fail(SC_ERR_ARG, "bad halo buffers");
+  if (!c->comm) return fail(SC_ERR_STATE, "sc_comm_init first");
+  if (c->in_step) return fail(SC_ERR_STATE, "halo exchange happens between ticks");
+  if ((left_rank >= 0 && (!send_left || !recv_left || left_rank >= c->comm_world)) ||
+      (right_rank >= 0 && (!send_right || !recv_right || right_rank >= c->comm_world)))
+    return fail(SC_ERR_ARG, "neighbor ranks %d / %d need their buffers and must be below %d", left_rank, right_rank,
+                c->comm_world);
+  const size_t count = (size_t)(cap_records + 1) * kHaloFields;
+  const RcclApi& r = rccl_api();
+  HIPCHK(hipSetDevice(c->device));
+  RCCLCHK(r.GroupStart());
+  int rc = 0;
+  // posting order is the same on every rank (left pair, then right pair): rank k's right pair meets rank k+1's left pair
+  if (left_rank >= 0) {
+    if (!rc) rc = r.Send(send_left, count, kRcclDouble, left_rank, c->comm, c->stream);
+    if (!rc) rc = r.Recv(recv_left, count, kRcclDouble, left_rank, c->comm, c->stream);
+  }
+  if (right_rank >= 0) {
+    if (!rc) rc = r.Send(send_right, count, kRcclDouble, right_rank, c->comm, c->stream);
+    if (!rc) rc = r.Recv(recv_right, count, kRcclDouble, right_rank, c->comm, c->stream);
+  }
+  const int rc_end = r.GroupEnd();
+  if (rc) return fail(SC_ERR_HIP, "RCCL: send/recv failed: %s", rccl_error(rc));
+  if (rc_end) return fail(SC_ERR_HIP, "RCCL: ncclGroupEnd failed: %s", rccl_error(rc_end));
   return SC_OK;
 }
 

@@ -226,6 +226,30 @@ class Engine:
         N.check(self._lib.sc_halo_unpack(self._ctx, N._P(dev_from_left) if dev_from_left else None,
                                          N._P(dev_from_right) if dev_from_right else None, int(capacity_records)))
 
+    # -- RCCL transport of the halo exchange (optional; see the header)
+    @staticmethod
+    def comm_unique_id(rccl_path: str | None = None) -> bytes:
+        buf = C.create_string_buffer(128)
+        N.check(N.load().sc_comm_unique_id(rccl_path.encode() if rccl_path else None, C.cast(buf, N._P)))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int, rccl_path: str | None = None) -> None:
+        if len(unique_id) != 128:
+            raise ValueError("an RCCL unique id is 128 bytes")
+        buf = C.create_string_buffer(unique_id, 128)
+        N.check(self._lib.sc_comm_init(self._ctx, rccl_path.encode() if rccl_path else None, C.cast(buf, N._P),
+                                       int(rank), int(world)))
+
+    def comm_destroy(self) -> None:
+        N.check(self._lib.sc_comm_destroy(self._ctx))
+
+    def halo_exchange(self, send_left: int | None, recv_left: int | None, left_rank: int, send_right: int | None,
+                      recv_right: int | None, right_rank: int, capacity_records: int) -> None:
+        """Device pointers as ints; a negative rank = no neighbor on that side.  Enqueued on the context's stream."""
+        ptr = lambda a: N._P(a) if a else None  # noqa: E731
+        N.check(self._lib.sc_halo_exchange(self._ctx, ptr(send_left), ptr(recv_left), int(left_rank), ptr(send_right),
+                                           ptr(recv_right), int(right_rank), int(capacity_records)))
+
     def owned_count(self) -> int:
         n = C.c_int64(0)
         N.check(self._lib.sc_owned_count(self._ctx, C.byref(n)))

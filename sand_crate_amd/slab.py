@@ -26,6 +26,7 @@ from __future__ import annotations
 
 import copy
 import math
+import os
 
 import numpy as np
 
@@ -112,6 +113,18 @@ class HipSlabBackend:
         self.engine.halo_unpack(self.recv_left.data_ptr() if from_left else None,
                                 self.recv_right.data_ptr() if from_right else None, self.halo_capacity)
 
+    def bundled_rccl(self) -> str | None:
+        """torch's own librccl, the fallback path for dlopen when no copy is loaded yet."""
+        import os
+        cand = os.path.join(os.path.dirname(self.torch.__file__), "lib", "librccl.so")
+        return cand if os.path.exists(cand) else None
+
+    def exchange_rccl(self, left: int | None, right: int | None) -> None:
+        """One RCCL group on the engine's stream: send/recv with both neighbors (sc_halo_exchange)."""
+        self.engine.halo_exchange(self.send_left.data_ptr(), self.recv_left.data_ptr(), -1 if left is None else left,
+                                  self.send_right.data_ptr(), self.recv_right.data_ptr(),
+                                  -1 if right is None else right, self.halo_capacity)
+
     def step(self, next_inputs=None) -> None:
         """The tick, one library call.  With the next tick's inputs promised, the force kernel also runs that
         tick's removal / wall pass and packs its halo message into the send buffers (sc_set_next_inputs)."""
@@ -135,7 +148,7 @@ class SlabCrate:
 
     def __init__(self, world_config, particles, velocities, *, device: int = 0, noise: str = "counter",
                  noise_seed: int = 0, group=None, backend=None, halo_capacity: int | None = None,
-                 capacity: int | None = None):
+                 capacity: int | None = None, transport: str | None = None):
         import torch.distributed as dist
         if noise == "host":
             raise ValueError("slabs need noise='counter' or 'none' (the host MT19937 stream is one global sequence)")
@@ -177,6 +190,12 @@ class SlabCrate:
         self._host_staged = dist.is_initialized() and dist.get_backend(group) != "nccl"
         self._stage = {}
         self._ops = None
+        self.transport = "torch"
+        want = (transport or os.environ.get("SANDCRATE_TRANSPORT", "rccl")).lower()
+        if want not in ("rccl", "torch"):
+            raise ValueError("transport must be 'rccl' or 'torch'")
+        if want == "rccl" and self.world > 1 and not self._host_staged and hasattr(self.backend, "exchange_rccl"):
+            self._try_rccl()
 
     # ------------------------------------------------------------------ stepping
     @property
@@ -188,11 +207,66 @@ class SlabCrate:
         seg, pad, bodies = tick_geometry(self.rigid_bodies, self.particle_radius, self._pad_cache)
         return coef, np.array(self.gravity, dtype=np.float64), seg, pad, bodies
 
+    def _try_rccl(self) -> None:
+        """Set up the library's own RCCL communicator for the slab chain and prove it with one exchange of a
+        known pattern; every step is agreed on by all ranks, so either all of them use it or none does (then
+        the torch.distributed P2P path stays)."""
+        import torch
+        from ._native import NativeError
+        dist, be = self.dist, self.backend
+        dev = be.device
+
+        def all_ok(ok: bool) -> bool:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            return bool(flag.item())
+
+        path = be.bundled_rccl()
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        ok = True
+        if self.rank == 0:
+            try:
+                uid = torch.frombuffer(bytearray(be.engine.comm_unique_id(path)), dtype=torch.uint8).to(dev)
+            except (NativeError, RuntimeError, OSError):
+                ok = False
+        if not all_ok(ok):
+            return
+        dist.broadcast(uid, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        try:
+            be.engine.comm_init(bytes(uid.cpu().numpy().tobytes()), self.rank, self.world, path)
+        except (NativeError, RuntimeError, OSError):
+            ok = False
+        if not all_ok(ok):
+            return
+        # proof: every rank sends (rank, side) stamps and must receive its neighbors' stamps
+        try:
+            be.send_left.fill_(float(2 * self.rank))
+            be.send_right.fill_(float(2 * self.rank + 1))
+            be.recv_left.fill_(-1.0)
+            be.recv_right.fill_(-1.0)
+            be.exchange_rccl(self.left, self.right)
+            be.engine.synchronize()
+            torch.cuda.synchronize(dev)
+            if self.left is not None:
+                ok = ok and bool((be.recv_left == float(2 * self.left + 1)).all().item())
+            if self.right is not None:
+                ok = ok and bool((be.recv_right == float(2 * self.right)).all().item())
+        except (NativeError, RuntimeError):
+            ok = False
+        for t in (be.send_left, be.send_right, be.recv_left, be.recv_right):
+            t.zero_()
+        torch.cuda.synchronize(dev)
+        if all_ok(ok):
+            self.transport = "rccl"
+
     def _exchange(self) -> None:
         """One message each way with each existing neighbor."""
         if self.world == 1:
             return
         dist, be = self.dist, self.backend
+        if self.transport == "rccl":
+            be.exchange_rccl(self.left, self.right)
+            return
         pairs = []  # (peer, send tensor, recv tensor)
         if self.left is not None:
             pairs.append((self.left, be.send_left, be.recv_left))

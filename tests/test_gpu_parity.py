@@ -598,3 +598,19 @@ def test_lookahead_promise_is_binding(sc):
     eng.step_begin()                                                 # the promised inputs: fine
     eng.step_finish()
     assert eng.count() == 200
+
+
+# ------------------------------------------------------------------ RCCL transport (one rank talking to itself)
+def test_rccl_transport_moves_halo_buffers_in_stream_order(sc):
+    """sc_comm_init / sc_halo_exchange on the only GPU there is here: a one-rank communicator whose left and
+    right neighbor is the rank itself (tests/rccl_worker.py, in a fresh process so that torch initialises the
+    GPU first, as in bench.py).  Proves the dlopen()ed RCCL entry points, the group of two send/recv pairs and
+    the ordering with the packing kernel on the same stream; the multi-rank pairing cannot be run on one device
+    (RCCL refuses two ranks per GPU)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    worker = Path(__file__).resolve().parent / "rccl_worker.py"
+    res = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    assert "RCCL_SELF_EXCHANGE_OK" in res.stdout
