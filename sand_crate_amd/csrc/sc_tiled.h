@@ -428,59 +428,93 @@ __global__ void __launch_bounds__(kTileW)
 // apply_particles_velocity (:360-361).  Reads the sorted arrays (through the LDS tile), writes the
 // storage arrays in the same order: that is the next tick's input.
 // ------------------------------------------------------------------------------------------
-struct Rec {
-  double x, y, vx, vy, P, sx, sy, pad;
+// The tile of pass B in LDS: (x, y), (sx, sy) and P of the three ranges -- 40 bytes per entry, 19 KiB,
+// so that eight workgroups share a CU (a 64-byte record with the velocities allowed five).  The
+// neighbors' start-of-tick velocities are only summed (crate.py:175, :319-323): they are staged into the
+// (x, y) array once the pair loop is done with it.
+struct PairSums {
+  double tx, ty, qx, qy;
 };
 
-// Phases 3-4 of pass B for one particle.  LDS: where the tile is (compile time, see the header).
-// js[] are neighbor-table entries (tile slots, or -(index+1)); `self` is the particle's own slot.
+// Phase 3a of pass B for one particle: the pair loop.  LDS: where the tile is (compile time, see the
+// header).  js[] are neighbor-table entries (tile slots, or -(index+1)); `self` is the particle's own slot.
 template <int NOISE, bool LDS>
-__device__ __forceinline__ void pass_b_body(const World& w, const Tile& tl, const Rec* tile, const int i, const int self,
-                                            const int C, const int Cn, const int ws, const int idi,
-                                            const int (&js)[kMaxNbr], const double* __restrict__ x,
-                                            const double* __restrict__ y, const double* __restrict__ vx,
-                                            const double* __restrict__ vy, const double* __restrict__ eta,
-                                            const int* __restrict__ offById, const double* __restrict__ P,
-                                            const double* __restrict__ sx, const double* __restrict__ sy,
-                                            const double* __restrict__ wrec, double& xn, double& yn, double& vxn,
-                                            double& vyn) {
-  auto load_rec = [&](int e) -> Rec {
+__device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl, const XY* txy, const XY* tss,
+                                                 const double* tP, const int self, const int Cn, const int idi,
+                                                 const int (&js)[kMaxNbr], const double* __restrict__ x,
+                                                 const double* __restrict__ y, const double* __restrict__ eta,
+                                                 const int* __restrict__ offById, const double* __restrict__ P,
+                                                 const double* __restrict__ sx, const double* __restrict__ sy,
+                                                 double& xi, double& yi, double& Pi) {
+  auto load = [&](int e, XY& pos, XY& nrm, double& pr) {
     if constexpr (LDS) {
-      return tile[e];
+      pos = txy[e];
+      nrm = tss[e];
+      pr = tP[e];
     } else {
       const int j = entry_index(tl, e);
-      return Rec{x[j], y[j], vx[j], vy[j], P[j], sx[j], sy[j], 0.0};
+      pos = XY{x[j], y[j]};
+      nrm = XY{sx[j], sy[j]};
+      pr = P[j];
     }
   };
-
-  // 3. pair math
-  const Rec me = load_rec(self);
-  const double xi = me.x, yi = me.y, Pi = me.P, sxi = me.sx, syi = me.sy;
-  double vxi = me.vx, vyi = me.vy;
+  XY mp, ms;
+  load(self, mp, ms, Pi);
+  xi = mp.x;
+  yi = mp.y;
+  const double sxi = ms.x, syi = ms.y;
   const int off = (NOISE == SC_NOISE_HOST) ? offById[idi] : 0;
   const uint64_t zbase = noise_base(w.noise_key, idi);
-  double tx = 0, ty = 0, qx = 0, qy = 0, ux = 0, uy = 0;
+  double tx = 0, ty = 0, qx = 0, qy = 0;
 #pragma unroll
   for (int s = 0; s < kMaxNbr; ++s) {
     if (s < Cn) {
-      const Rec o = load_rec(js[s]);
+      XY op, os;
+      double oP;
+      load(js[s], op, os, oP);
       double ex, ey;
       collider_noise<NOISE>(w, zbase + (uint64_t)s * kGold, s, eta, off, ex, ey);
-      const double rx = xi - (o.x + ex), ry = yi - (o.y + ey);
+      const double rx = xi - (op.x + ex), ry = yi - (op.y + ey);
       const double rinv = rsqrt_nr(rx * rx + ry * ry);
       const double nx = rx * rinv, ny = ry * rinv;
-      const double align = ((sxi - o.sx) * nx + (syi - o.sy) * ny) * w.ss;  // crate.py:347-349
-      const double fix = o.P + Pi - 2 * w.tp;                                // crate.py:351
+      const double align = ((sxi - os.x) * nx + (syi - os.y) * ny) * w.ss;  // crate.py:347-349
+      const double fix = oP + Pi - 2 * w.tp;                                 // crate.py:351
       const double kk = align + fix;
       tx += kk * nx;
       ty += kk * ny;
-      const double pp = Pi + o.P;  // crate.py:301-304
+      const double pp = Pi + oP;  // crate.py:301-304
       qx += nx * pp;
       qy += ny * pp;
-      ux += o.vx;  // crate.py:175: the neighbors' start-of-tick velocities
-      uy += o.vy;
     }
   }
+  return PairSums{tx, ty, qx, qy};
+}
+
+// Phases 3b-4 of pass B for one particle: the sum of the neighbors' start-of-tick velocities (from `tv`,
+// the (vx, vy) of the tile, or from global memory) and the per-particle epilogue.
+template <bool LDS>
+__device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, const XY* tv, const int C, const int Cn,
+                                              const int ws, const int (&js)[kMaxNbr], const double* __restrict__ vx,
+                                              const double* __restrict__ vy, const double* __restrict__ wrec,
+                                              const PairSums ps, const double xi, const double yi, const double Pi,
+                                              double vxi, double vyi, double& xn, double& yn, double& vxn, double& vyn) {
+  double ux = 0, uy = 0;
+#pragma unroll
+  for (int s = 0; s < kMaxNbr; ++s) {
+    if (s < Cn) {
+      XY ov;
+      if constexpr (LDS) {
+        ov = tv[js[s]];
+      } else {
+        const int j = entry_index(tl, js[s]);
+        ov = XY{vx[j], vy[j]};
+      }
+      ux += ov.x;  // crate.py:175: the neighbors' start-of-tick velocities
+      uy += ov.y;
+    }
+  }
+  const double tx = ps.tx, ty = ps.ty;
+  double qx = ps.qx, qy = ps.qy;
 
   // 4. per-particle epilogue
   vxi += w.dt * tx;  // crate.py:352
@@ -565,7 +599,9 @@ __global__ void __launch_bounds__(kTileW)
              WallInputs wn, int* __restrict__ cellS, int* __restrict__ wslotS, int* __restrict__ cellCount,
              double* __restrict__ wrec_next, int wrec_counter_next, double* __restrict__ haloL,
              double* __restrict__ haloR, int haloCap) {
-  __shared__ Rec tile[kTileCapB];
+  __shared__ XY txy[kTileCapB];   // (x, y) of the tile; (vx, vy) once the pair loop is done
+  __shared__ XY tss[kTileCapB];   // (sx, sy)
+  __shared__ double tP[kTileCapB];
 
   const int t = threadIdx.x;
   const int tile_id = tile_of_block();
@@ -612,23 +648,33 @@ __global__ void __launch_bounds__(kTileW)
   const int Cn = ghost ? 0 : C;  // ghosts serve as neighbors only
   const int ws = live ? ws_raw : -1;
 
-  // 2. stage the seven arrays of the three ranges as interleaved records; every load of the
-  // tile is in flight before the first LDS write
+  // 2. stage the three ranges; every load of the tile is in flight before the first LDS write.  The
+  // velocities wait in registers for their turn in the (x, y) array.
+  constexpr int kPer = (kTileCapB + kTileW - 1) / kTileW;
+  XY rv[kPer];
+  const double vx0 = vx[ic], vy0 = vy[ic];
   if (in_lds) {
-    constexpr int kPer = (kTileCapB + kTileW - 1) / kTileW;
-    Rec r[kPer];
+    XY rp[kPer], rs[kPer];
+    double rP[kPer];
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
       const int s = t + k * kTileW;
       if (s < total) {
         const int j = tile_index(tl, s);
-        r[k] = Rec{x[j], y[j], vx[j], vy[j], P[j], sx[j], sy[j], 0.0};
+        rp[k] = XY{x[j], y[j]};
+        rs[k] = XY{sx[j], sy[j]};
+        rP[k] = P[j];
+        rv[k] = XY{vx[j], vy[j]};
       }
     }
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
       const int s = t + k * kTileW;
-      if (s < total) tile[s] = r[k];
+      if (s < total) {
+        txy[s] = rp[k];
+        tss[s] = rs[k];
+        tP[s] = rP[k];
+      }
     }
   }
   __syncthreads();
@@ -637,15 +683,27 @@ __global__ void __launch_bounds__(kTileW)
   double xn = __builtin_huge_val(), yn = 0.0, vxn = 0.0, vyn = 0.0;  // a ghost's copy: +inf makes the next
   int idn = -1;                                                        // removal test (crate.py:152) drop it
   const bool active = live && !ghost;
-  if (active) {
-    const int self = i - tl.a0;
+  const int self = i - tl.a0;
+  if (in_lds) {
+    PairSums ps{0, 0, 0, 0};
+    double xi = 0, yi = 0, Pi = 0;
+    if (active) ps = pass_b_pairs<NOISE, true>(w, tl, txy, tss, tP, self, Cn, idi, js, x, y, eta, offById, P, sx, sy, xi, yi, Pi);
+    __syncthreads();  // everybody is done with (x, y): the array now takes the velocities
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int s = t + k * kTileW;
+      if (s < total) txy[s] = rv[k];
+    }
+    __syncthreads();
+    if (active) {
+      idn = idi;
+      pass_b_finish<true>(w, tl, txy, C, Cn, ws, js, vx, vy, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn);
+    }
+  } else if (active) {
+    double xi, yi, Pi;
     idn = idi;
-    if (in_lds)
-      pass_b_body<NOISE, true>(w, tl, tile, i, self, C, Cn, ws, idi, js, x, y, vx, vy, eta, offById, P, sx, sy, wrec, xn,
-                               yn, vxn, vyn);
-    else
-      pass_b_body<NOISE, false>(w, tl, tile, i, self, C, Cn, ws, idi, js, x, y, vx, vy, eta, offById, P, sx, sy, wrec, xn,
-                                yn, vxn, vyn);
+    const PairSums ps = pass_b_pairs<NOISE, false>(w, tl, txy, tss, tP, self, Cn, idi, js, x, y, eta, offById, P, sx, sy, xi, yi, Pi);
+    pass_b_finish<false>(w, tl, txy, C, Cn, ws, js, vx, vy, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn);
   }
   if (FUSED) {
     int cnext = -1, wsn = -1;

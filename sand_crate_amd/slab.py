@@ -92,6 +92,7 @@ class HipSlabBackend:
         self._params_key = None
         self._inputs = None
         self.packed_ahead = False
+        self._promised = None
 
     def load(self, particles, velocities, ids) -> None:
         self.engine.upload_with_ids(particles, velocities, ids)
@@ -100,7 +101,10 @@ class HipSlabBackend:
         self.engine.set_slab(lo, hi, halo, has_left, has_right)
 
     def set_tick_inputs(self, coef, gravity, segments, padded, bodies) -> None:
-        self._inputs = self.engine.pack_inputs(coef, gravity, segments, padded, bodies)
+        if self._promised is not None and self._promised[0] is coef:  # the very inputs the last step() promised
+            self._inputs = self._promised[1]
+        else:
+            self._inputs = self.engine.pack_inputs(coef, gravity, segments, padded, bodies)
         key = (tuple(coef.values()), float(gravity[0]), float(gravity[1]))
         if key != self._params_key:  # the halo kernels need the grid (diameter) before the tick itself runs
             self.engine.set_params(gravity=gravity, **coef)
@@ -131,6 +135,7 @@ class HipSlabBackend:
         nxt = self.engine.pack_inputs(*next_inputs) if next_inputs is not None else None
         self.engine.tick(self._inputs, nxt)
         self.packed_ahead = nxt is not None
+        self._promised = (next_inputs[0], nxt) if nxt is not None else None
 
     def synchronize(self) -> None:
         self.engine.synchronize()
