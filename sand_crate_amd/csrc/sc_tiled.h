@@ -274,6 +274,8 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
 
   // 4. pair math of pass A: populate_colliders (crate.py:161-175), pressures (:261-275), normals (:337-342)
   if (DENS && live) {
+    // nothing here feeds a decision: multiply-adds may fuse (the file is compiled with -ffp-contract=off)
+#pragma clang fp contract(fast)
     double sumw = 0, ax = 0, ay = 0;
     const int off = (NOISE == SC_NOISE_HOST) ? offById[idi] : 0;
     uint64_t z = noise_base(w.noise_key, idi);
@@ -446,6 +448,8 @@ __device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl,
                                                  const int* __restrict__ offById, const double* __restrict__ P,
                                                  const double* __restrict__ sx, const double* __restrict__ sy,
                                                  double& xi, double& yi, double& Pi) {
+  // nothing here feeds a decision: multiply-adds may fuse (the file is compiled with -ffp-contract=off)
+#pragma clang fp contract(fast)
   auto load = [&](int e, XY& pos, XY& nrm, double& pr) {
     if constexpr (LDS) {
       pos = txy[e];
@@ -517,11 +521,13 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
   double qx = ps.qx, qy = ps.qy;
 
   // 4. per-particle epilogue
+  double Ux = 0, Uy = 0, Cx = 0, Cy = 0, V = 0;
+  {
+#pragma clang fp contract(fast)
   vxi += w.dt * tx;  // crate.py:352
   vyi += w.dt * ty;
   vxi += w.dt * w.gx;  // crate.py:310
   vyi += w.dt * w.gy;
-  double Ux = 0, Uy = 0, Cx = 0, Cy = 0, V = 0;
   if (ws >= 0) {
     const double* rec = wrec + 5 * (size_t)ws;
     Ux = rec[0]; Uy = rec[1]; Cx = rec[2]; Cy = rec[3]; V = rec[4];
@@ -534,6 +540,7 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
   const double dv = w.dt * w.visc;  // crate.py:319-323: sum_j (v0_j - v_i), v_i the current velocity
   vxi += dv * (ux - C * vxi);
   vyi += dv * (uy - C * vyi);
+  }
   if (ws >= 0) {  // crate.py:245-259
     double nx = Ux / V, ny = Uy / V;
     const double nn = sqrt(nx * nx + ny * ny);
