@@ -93,6 +93,8 @@ class Crate:
         self._empty()
         self._tick_seconds = 0.0   # EMA of wall time per tick, for debug_prints
         self._pad_cache = {}
+        self._hud_kernels = False
+        self._kernel_seconds = {}
         self.last_stats = None
 
     # ------------------------------------------------------------------ reference accessors
@@ -194,9 +196,25 @@ class Crate:
                 body.center_velocity = body.center_velocity + self.dt * self.gravity
         self._cache = None
         self.tick += 1
+        if self._hud_kernels:  # the HUD's phase split (timer.py:37-48), from HIP events; synchronises the tick
+            eng.synchronize()
+            for name, (ms, launches) in eng.timing().items():
+                if launches:
+                    self._kernel_seconds[name] = 0.9 * self._kernel_seconds.get(name, 0.0) + 0.1 * ms / 1000.0
+            eng.reset_timing()
         dt_wall = time.perf_counter() - t0
         self._tick_seconds = 0.9 * self._tick_seconds + 0.1 * dt_wall
         self.set_debug_prints()
+
+    def show_kernel_times(self, on: bool = True) -> None:
+        """The reference's HUD splits the frame into its Python phases (crate.py:93-125 under
+        `debug_timer`, reported by timer.py:37-48).  The phases are fused into kernels here; with this on,
+        `physics_tick` brackets every launch with HIP events and `debug_prints` shows the same
+        `Timing: {name: "x ms (y%)"}` block per kernel.  Costs one synchronisation per tick."""
+        self._hud_kernels = bool(on)
+        self._kernel_seconds = {}
+        self._engine.reset_timing()
+        self._engine.enable_timing(self._hud_kernels)
 
     def run(self, n_ticks: int) -> None:
         """`n_ticks` ticks back to back without touching the host state in between (no sources
@@ -261,9 +279,13 @@ class Crate:
     def set_debug_prints(self) -> None:
         count = self._count if self._count_known else "?"
         self.debug_prints = f"Tick: {self.tick}\nParticles: {count}\n"
-        ms = 1000 * self._tick_seconds
-        self.debug_prints += yaml.dump({"Timing": {"tick (host wall, EMA)": f"{ms:.2f} ms"},
-                                        "FPS": f"{int(1 / self._tick_seconds) if self._tick_seconds > 0 else 0}"})
+        frame = self._tick_seconds
+        timing = {"tick (host wall, EMA)": f"{1000 * frame:.2f} ms"}
+        if self._hud_kernels and frame > 0:
+            for name, seconds in self._kernel_seconds.items():
+                timing[name] = f"{1000 * seconds:.3f} ms ({100 * seconds / frame:.0f}%)"
+        self.debug_prints += yaml.dump({"Timing": timing,
+                                        "FPS": f"{int(1 / frame) if frame > 0 else 0} ({1000 * frame:.0f} ms)"})
         self.debug_prints += f"\n\n{self.get_coefficient_debug()}"
 
     def get_coefficient_debug(self) -> str:

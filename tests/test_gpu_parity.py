@@ -614,3 +614,22 @@ def test_rccl_transport_moves_halo_buffers_in_stream_order(sc):
     res = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     assert "RCCL_SELF_EXCHANGE_OK" in res.stdout
+
+
+def test_hud_shows_kernel_times(sc):
+    """N4 of SURVEY.md section 8f: `debug_prints` keeps the reference's layout (crate.py:131-136, timer.py:37-48):
+    tick, particle count, a `Timing` block -- per kernel when asked for -- `FPS`, the coefficients."""
+    import yaml
+    cfg = sc.load_config("config/stirring_cup.yaml")
+    crate = sc.Crate(cfg.world_config)
+    crate.show_kernel_times()
+    for _ in range(12):
+        crate.physics_tick()
+    text = crate.debug_prints
+    assert text.startswith("Tick: 12\nParticles: ")
+    head = yaml.safe_load(text.split("\n\n")[0].split("\n", 2)[2])
+    assert {"force_integrate", "reorder", "wall_bin"} <= set(head["Timing"]) and "FPS" in head
+    assert all("ms" in v for v in head["Timing"].values())
+    crate.show_kernel_times(False)
+    crate.physics_tick()
+    assert "force_integrate" not in crate.debug_prints and "particle_radius" in crate.debug_prints
