@@ -234,7 +234,10 @@ def main() -> None:
             gbps = ALGO_BYTES.get(name, 0) * per_gpu / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
             kernels[name] = {"avg_us": round(avg_us, 3), "launches": launches, "us_per_tick": round(1000.0 * ms / args.steps, 3),
                              "algo_bytes_per_particle": ALGO_BYTES.get(name, 0), "achieved_GBps": round(gbps, 1)}
-        dom = max((k for k in kernels if ALGO_BYTES.get(k, 0) > 0), key=lambda k: kernels[k]["avg_us"])
+        # BASELINE.json's metric is "% HBM-BW roofline in force kernel": the roofline object describes the fused
+        # force + integrate kernel (pass B).  Pass A takes about the same time per tick; it, the pair and the
+        # whole tick are reported next to it.
+        dom = "force_integrate"
         tick_us = sum(k["us_per_tick"] for k in kernels.values())  # kernels that run once in a while count by their share
         pass_a = "neighbors_density" if "neighbors_density" in kernels else "density"
         force_us = kernels[pass_a]["avg_us"] + kernels["force_integrate"]["avg_us"]
@@ -248,6 +251,9 @@ def main() -> None:
             "measured_over": f"a replay of the same {args.warmup}+{args.steps} ticks from the same initial state right after the timed region, HIP events around every launch",
             "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * per_gpu,
             "avg_launch_us": kernels[dom]["avg_us"],
+            "pass_a": {"kernel": pass_a, "bytes_per_particle": ALGO_BYTES[pass_a], "us": kernels[pass_a]["avg_us"],
+                       "achieved_GBps": kernels[pass_a]["achieved_GBps"],
+                       "frac": round(kernels[pass_a]["achieved_GBps"] / HBM_PEAK_GBPS, 5)},
             "force_pair": {"kernels": f"{pass_a} + force_integrate", "bytes_per_particle": FORCE_BYTES,
                            "us": round(force_us, 3),
                            "achieved_GBps": round(FORCE_BYTES * per_gpu / (force_us * 1e-6) / 1e9, 1),

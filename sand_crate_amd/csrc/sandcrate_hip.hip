@@ -636,7 +636,9 @@ int sc_step_begin(sc_ctx* c) {
     int spins = 0;
     while (c->tick - (int64_t) * (volatile int*)(c->bigHintHost + 1) > kMaxTicksQueued) {
       if (++spins > 64) {
-        if (hipStreamQuery(c->stream) == hipSuccess) break;  // nothing queued: the counter is simply behind (re-upload)
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) break;  // nothing queued: the counter is simply behind (re-upload)
+        if (q != hipErrorNotReady) return fail(SC_ERR_HIP, "stream error while waiting for queued ticks: %s", hipGetErrorString(q));
         spins = 0;
       }
       sched_yield();
