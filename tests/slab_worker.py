@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--noise", default="counter")
     ap.add_argument("--margin", type=float, default=0.0)
     ap.add_argument("--mixed", action="store_true", help="run(2), physics_tick(), run(rest): look-ahead on and off")
+    ap.add_argument("--halo-capacity", type=int, default=0, help="records per halo message (0 = SlabCrate's default)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     import torch.distributed as dist
@@ -45,7 +46,8 @@ def main():
     if a.backend == "oracle":
         from slab_oracle_backend import OracleSlabBackend
         backend = OracleSlabBackend(halo_capacity=a.particles, noise=a.noise, noise_seed=9)
-    sim = SlabCrate(wc, p, v, device=0, noise=a.noise, noise_seed=9, backend=backend)
+    sim = SlabCrate(wc, p, v, device=0, noise=a.noise, noise_seed=9, backend=backend,
+                    halo_capacity=a.halo_capacity or None)
     if a.mixed:
         sim.run(2)
         sim.physics_tick()

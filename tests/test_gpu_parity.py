@@ -633,3 +633,89 @@ def test_hud_shows_kernel_times(sc):
     crate.show_kernel_times(False)
     crate.physics_tick()
     assert "force_integrate" not in crate.debug_prints and "particle_radius" in crate.debug_prints
+
+
+# ------------------------------------------------------------------ more edge cases of the machinery
+def _coef_of(crate):
+    return {k: getattr(crate, k) for k in ("dt", "particle_radius", "wall_collision_decay", "pressure_amplifier",
+                                           "ignored_pressure", "collider_noise_level", "viscosity", "surface_smoothing",
+                                           "target_pressure")}
+
+
+def test_lookahead_survives_a_promised_radius_change(sc):
+    """The promised tick may have another particle radius: another cell grid (re-allocated when it grows),
+    other wall thresholds.  sc_tick(now, next) + sc_tick(next) must equal two unpromised ticks."""
+    from sand_crate_amd.crate import tick_geometry
+    n = 20000
+    p, v, d = synthetic(n, seed=31, margin=0.02, vel=2.0)
+    results = []
+    for promised in (True, False):
+        crate = sc.Crate(wave_world(sc, d, 0.1), noise="counter", noise_seed=3, capacity=n + 16)
+        crate.particles, crate.particle_velocities = p, v
+        eng = crate.engine
+        packs = []
+        for radius in (d / 2, d / 2 * 0.8, d / 2 * 1.1):
+            for b in crate.rigid_bodies:
+                b.apply_velocity(crate.dt)
+            crate.particle_radius = radius
+            seg, pad, bodies = tick_geometry(crate.rigid_bodies, radius, {})
+            packs.append(eng.pack_inputs(_coef_of(crate), crate.gravity, seg, pad, bodies))
+        for k, now in enumerate(packs):
+            eng.tick(now, packs[k + 1] if promised and k + 1 < len(packs) else None)
+        results.append(eng.download())
+    for a, b in zip(*results):
+        assert np.array_equal(a, b)
+
+
+def test_tick_reports_a_bad_promise_and_stays_usable(sc):
+    from sand_crate_amd import _native as N
+    from sand_crate_amd.crate import tick_geometry
+    wc = wave_world(sc, 0.02, 0.0)
+    crate = sc.Crate(wc, noise="none")
+    pts = np.random.RandomState(1).rand(300, 2) * 0.8 + 0.1
+    crate.particles, crate.particle_velocities = pts, np.zeros_like(pts)
+    eng = crate.engine
+    seg, pad, bodies = tick_geometry(crate.rigid_bodies, crate.particle_radius, {})
+    good = eng.pack_inputs(_coef_of(crate), crate.gravity, seg, pad, bodies)
+    many = np.tile(seg, (5, 1, 1))[:33]                       # 33 segments: one more than the library takes
+    bad = eng.pack_inputs(_coef_of(crate), crate.gravity, many, sc.pad_segments(many, crate.particle_radius),
+                          [((0, 0), (0, 0), 0.0, 33)])
+    with pytest.raises(N.NativeError, match="segments"):
+        eng.tick(good, bad)
+    eng.tick(good, good)                                       # the tick itself was completed; carry on
+    eng.tick(good)
+    assert eng.count() == 300
+
+
+def test_more_big_buckets_than_the_rank_kernel_lists(sc):
+    """k_rank_big takes the first 1024 big buckets of a tick; the rest is ranked inside the reorder kernel.
+    1150 cells of 100 particles each, with x ties: the sorted order must still be the reference's."""
+    from oracle.neighbors import strip_sort
+    rs = np.random.RandomState(8)
+    d = 0.02
+    cells = rs.permutation(45 * 45)[:1150]
+    cx, cy = (cells % 45 + 2) * d, (cells // 45 + 2) * d
+    pts = np.column_stack(((cx[:, None] + np.round(rs.rand(1150, 100) * 8) / 8 * d * 0.9).ravel(),
+                           (cy[:, None] + rs.rand(1150, 100) * d * 0.99).ravel()))
+    pts = pts[rs.permutation(len(pts))]
+    rows, order, counts, table = sc.neighbor_search(pts, d)
+    ref_rows, ref_order = strip_sort(pts, d)
+    assert np.array_equal(rows, ref_rows) and np.array_equal(order, ref_order)
+    assert counts.min() == 20                                  # every particle has a full list in such a cell
+
+
+def test_halo_buffer_overflow_is_reported(sc, tmp_path):
+    """A halo message that cannot hold the band is never silently truncated: the ranks fail with the
+    library's message at the next synchronising call."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_slab_gloo_cpu import free_port
+    root = Path(__file__).resolve().parent.parent
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(root / "tests" / "slab_worker.py"), "--out", str(tmp_path / "x.npz"),
+           "--backend", "hip", "--particles", "40000", "--ticks", "3", "--halo-capacity", "64"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode != 0
+    assert "a halo buffer was too small" in res.stderr
