@@ -332,7 +332,6 @@ WallInputs wall_inputs_of(const World& w) {
   return k;
 }
 
-int wrec_counter_of(int64_t tick) { return (tick & 1) ? C_WREC2 : C_WREC; }
 
 int read_counters(sc_ctx* c, int* out) {
   HIPCHK(hipMemcpyAsync(out, c->counters, C_COUNT * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -429,8 +428,8 @@ void launch_pass_b(sc_ctx* c, const WallInputs& wn) {
   hipLaunchKernelGGL((k_pass_b<NOISE, FUSED>), dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters, c->x[1],
                      c->y[1], c->vx[1], c->vy[1], c->id[1], c->wslotT, c->cellT, c->nbr, c->cnt, (int)c->cap, c->eta,
                      c->offById, c->P, c->sx, c->sy, c->wrec[cur], c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0],
-                     c->tileBounds, c->bigHintDev, wrec_counter_of(c->tick), wn, c->cellS, c->wslotS, c->cellCount,
-                     c->wrec[nxt], wrec_counter_of(c->tick + 1), c->haloL, c->haloR, c->haloCap);
+                     c->tileBounds, c->bigHintDev, wn, c->cellS, c->wslotS, c->cellCount, c->wrec[nxt], c->haloL, c->haloR,
+                     c->haloCap);
 }
 
 template <int NOISE>
@@ -658,7 +657,7 @@ int sc_step_begin(sc_ctx* c) {
   } else {
     Bracket br(c, K_WALL_BIN);
     hipLaunchKernelGGL(k_wall_bin, dim3(grid), dim3(kBlock), 0, c->stream, w, c->counters, c->x[0], c->y[0], c->cellS,
-                       c->wslotS, c->cellCount, c->wrec[c->tick & 1], cap, wrec_counter_of(c->tick));
+                       c->wslotS, c->cellCount, c->wrec[c->tick & 1], cap);
   }
   {
     Bracket br(c, K_SCAN);
@@ -713,14 +712,14 @@ int sc_step_begin(sc_ctx* c) {
 int sc_step_stats(sc_ctx* c, sc_stats* out) {
   if (!c || !out) return fail(SC_ERR_ARG, "null argument");
   if (!c->in_step) return fail(SC_ERR_STATE, "sc_step_stats needs sc_step_begin first");
-  hipLaunchKernelGGL(k_count_stats, dim3(1), dim3(kBlock), 0, c->stream, c->counters, c->cnt);
+  hipLaunchKernelGGL(k_count_stats, dim3(1), dim3(kBlock), 0, c->stream, c->counters, c->cnt, c->wslotT);
   int h[C_COUNT];
   int rc = read_counters(c, h);
   if (rc) return rc;
   out->particles = h[C_NT];
   out->neighbor_slots = (int64_t)(uint32_t)h[C_SUMC] + ((int64_t)h[C_SUMC_HI] << 32);
   out->max_neighbors = h[C_MAXC];
-  out->wall_particles = h[wrec_counter_of(c->tick)];
+  out->wall_particles = h[C_WREC];
   out->flags = h[C_FLAGS];
   out->reserved = 0;
   return SC_OK;
@@ -1132,13 +1131,13 @@ int sc_halo_unpack(sc_ctx* c, const double* from_left, const double* from_right,
   if (c->prebinned) {  // the stored particles went through K1 of the coming tick in pass B: same for the arrivals
     hipLaunchKernelGGL(k_halo_unpack<true>, grid, block, 0, c->stream, from_left, from_right, (int)cap_records,
                        c->counters, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], (int)c->cap, c->haloL, c->haloR,
-                       c->promised, c->cellS, c->wslotS, c->cellCount, c->wrec[c->tick & 1], wrec_counter_of(c->tick));
+                       c->promised, c->cellS, c->wslotS, c->cellCount, c->wrec[c->tick & 1]);
   } else {
     WallInputs none;
     std::memset(&none, 0, sizeof none);
     hipLaunchKernelGGL(k_halo_unpack<false>, grid, block, 0, c->stream, from_left, from_right, (int)cap_records,
                        c->counters, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], (int)c->cap, c->haloL, c->haloR, none,
-                       c->cellS, c->wslotS, c->cellCount, c->wrec[c->tick & 1], wrec_counter_of(c->tick));
+                       c->cellS, c->wslotS, c->cellCount, c->wrec[c->tick & 1]);
   }
   HIPCHK(hipGetLastError());
   return SC_OK;

@@ -72,8 +72,7 @@ enum Counter {
   C_NS = 0,     // particles in the storage arrays at the start of the tick
   C_NT = 1,     // live particles after removal (= entries of the sorted arrays)
   C_FLAGS = 2,  // error bits
-  C_WREC = 3,   // wall records appended for even ticks (odd ticks: C_WREC2); the two alternate so that
-                // pass B of tick t can read tick t's records while it writes tick t+1's (fused K1)
+  C_WREC = 3,   // particles with a wall record, counted on demand (sc_step_stats)
   C_SUMC = 4,   // sum of neighbor counts (low 32 bits)
   C_MAXC = 5,   // max neighbor count
   C_SUMC_HI = 6,

@@ -56,10 +56,12 @@ __global__ void k_bump(int* counters, int m, int reset) { counters[C_NS] = (rese
 // ------------------------------------------------------------------------------------------
 // The per-particle part of K1 on a position held in registers: returns the particle's packed cell
 // or -1 (removed), the wall-record slot in `wslot`, and the position after the hard wall fix in
-// (px, py).  W is World or WallInputs.  `wrec_counter` is the counter of the tick's record buffer.
+// (px, py).  W is World or WallInputs.  A particle in contact with a wall leaves its record at `rec` in the
+// tick's record buffer -- the caller passes the particle's own storage index, so that no shared counter
+// hands out slots (one returning atomic per wave on one address was the cost of a compact list).
 template <class W>
 __device__ __forceinline__ int wall_and_cell(const W& w, double& px, double& py, int& wslot, int* __restrict__ counters,
-                                             int wrec_counter, double* __restrict__ wrec) {
+                                             int rec, double* __restrict__ wrec) {
   wslot = -1;
   if (px < w.lo || px > w.hi || py < w.lo || py > w.hi) return -1;  // crate.py:152 (dead ghosts carry x = +inf)
   bool ghost = false;
@@ -127,13 +129,13 @@ __device__ __forceinline__ int wall_and_cell(const W& w, double& px, double& py,
       }
       px += fx;  // crate.py:211
       py += fy;
-      wslot = atomicAdd(&counters[wrec_counter], 1);
-      double* rec = wrec + 5 * (size_t)wslot;
-      rec[0] = Ux;
-      rec[1] = Uy;
-      rec[2] = Cx;
-      rec[3] = Cy;
-      rec[4] = (double)q;
+      wslot = rec;
+      double* out = wrec + 5 * (size_t)rec;
+      out[0] = Ux;
+      out[1] = Uy;
+      out[2] = Cx;
+      out[3] = Cy;
+      out[4] = (double)q;
     }
   }
   if (!(px == px) || !(py == py)) {  // crate.py:206: distance 0 to a wall gives NaN
@@ -159,7 +161,7 @@ __device__ __forceinline__ void count_cells(int c, int* __restrict__ cellCount) 
 __global__ void __launch_bounds__(kBlock) k_wall_bin(World w, int* __restrict__ counters, double* __restrict__ x,
                                                      double* __restrict__ y, int* __restrict__ cellS,
                                                      int* __restrict__ wslotS, int* __restrict__ cellCount,
-                                                     double* __restrict__ wrec, int cap, int wrec_counter) {
+                                                     double* __restrict__ wrec, int cap) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int ic = min(i, cap - 1);  // the position is requested before the stored count is waited for
   double px = x[ic], py = y[ic];
@@ -167,7 +169,7 @@ __global__ void __launch_bounds__(kBlock) k_wall_bin(World w, int* __restrict__ 
   int c = -1;
   if (i < counters[C_NS]) {
     int wslot;
-    c = wall_and_cell(w, px, py, wslot, counters, wrec_counter, wrec);
+    c = wall_and_cell(w, px, py, wslot, counters, i, wrec);
     cellS[i] = c;
     if (c >= 0) {
       wslotS[i] = wslot;
@@ -562,30 +564,35 @@ __global__ void __launch_bounds__(kReorderBlock)
 
 // Sum and maximum of the neighbor counts, on demand (sc_step_stats).  Kept out of the search kernel:
 // one atomic per workgroup on a single address serialises at ~12 ns each and dominated it.
-__global__ void __launch_bounds__(kBlock) k_count_stats(int* __restrict__ counters, const unsigned char* __restrict__ cnt) {
-  __shared__ int ssum[kBlock / 64], smax[kBlock / 64];
+__global__ void __launch_bounds__(kBlock) k_count_stats(int* __restrict__ counters, const unsigned char* __restrict__ cnt,
+                                                        const int* __restrict__ wslot) {
+  __shared__ int ssum[kBlock / 64], smax[kBlock / 64], swall[kBlock / 64];
   int n = counters[C_NT];
   long long sum = 0;
-  int mx = 0;
+  int mx = 0, walls = 0;
   for (int i = threadIdx.x; i < n; i += kBlock) {
     int c = cnt[i];
     sum += c;
     mx = max(mx, c);
+    walls += wslot[i] >= 0;  // particles with a wall record (crate.py:229: V_i not empty)
   }
   // counts are <= 20, so a lane's partial sum fits 32 bits for n < 1e8
-  int s32 = wave_sum((int)sum), m32 = wave_max(mx);
+  int s32 = wave_sum((int)sum), m32 = wave_max(mx), w32 = wave_sum(walls);
   if ((threadIdx.x & 63) == 0) {
     ssum[threadIdx.x >> 6] = s32;
     smax[threadIdx.x >> 6] = m32;
+    swall[threadIdx.x >> 6] = w32;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned long long tot = 0;
-    int m = 0;
+    int m = 0, wl = 0;
     for (int k = 0; k < kBlock / 64; ++k) {
       tot += (unsigned)ssum[k];
       m = max(m, smax[k]);
+      wl += swall[k];
     }
+    counters[C_WREC] = wl;
     counters[C_SUMC] = (int)(unsigned)(tot & 0xFFFFFFFFull);
     counters[C_SUMC_HI] = (int)(tot >> 32);
     counters[C_MAXC] = m;
@@ -687,7 +694,7 @@ __global__ void __launch_bounds__(kBlock)
                   double* __restrict__ x, double* __restrict__ y, double* __restrict__ vx, double* __restrict__ vy,
                   int* __restrict__ id, int capS, double* __restrict__ sendL, double* __restrict__ sendR, WallInputs wn,
                   int* __restrict__ cellS, int* __restrict__ wslotS, int* __restrict__ cellCount,
-                  double* __restrict__ wrec_next, int wrec_counter_next) {
+                  double* __restrict__ wrec_next) {
   const int nl = bufL ? min(*reinterpret_cast<const int*>(bufL), cap) : 0;
   const int nr = bufR ? min(*reinterpret_cast<const int*>(bufR), cap) : 0;
   const int base = FUSED ? counters[C_NT] : __hip_atomic_load(&counters[C_NS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -701,7 +708,7 @@ __global__ void __launch_bounds__(kBlock)
       double px = r[0], py = r[1];
       if (FUSED) {
         int wsn = -1;
-        cnext = wall_and_cell(wn, px, py, wsn, counters, wrec_counter_next, wrec_next);
+        cnext = wall_and_cell(wn, px, py, wsn, counters, base + k, wrec_next);
         cellS[base + k] = cnext;
         if (cnext >= 0) wslotS[base + k] = wsn;
       }

@@ -602,9 +602,9 @@ __global__ void __launch_bounds__(kTileW)
              const int* __restrict__ offById, const double* __restrict__ P, const double* __restrict__ sx,
              const double* __restrict__ sy, const double* __restrict__ wrec, double* __restrict__ xo,
              double* __restrict__ yo, double* __restrict__ vxo, double* __restrict__ vyo, int* __restrict__ ido,
-             const int* __restrict__ tileBounds, volatile int* __restrict__ progress, int wrec_counter,
+             const int* __restrict__ tileBounds, volatile int* __restrict__ progress,
              WallInputs wn, int* __restrict__ cellS, int* __restrict__ wslotS, int* __restrict__ cellCount,
-             double* __restrict__ wrec_next, int wrec_counter_next, double* __restrict__ haloL,
+             double* __restrict__ wrec_next, double* __restrict__ haloL,
              double* __restrict__ haloR, int haloCap) {
   __shared__ XY txy[kTileCapB];   // (x, y) of the tile; (vx, vy) once the pair loop is done
   __shared__ XY tss[kTileCapB];   // (sx, sy)
@@ -629,8 +629,8 @@ __global__ void __launch_bounds__(kTileW)
   const int n = counters[C_NT];
   if (tile_id == 0 && t == 0) {
     counters[C_NS] = n;    // the storage arrays now hold the n live particles
-    counters[wrec_counter] = 0;  // per-tick counters start the next tick at zero (sc_step_stats reads them
-    counters[C_SUMC] = 0;  // between sc_step_begin and sc_step_finish, i.e. before this kernel)
+    counters[C_SUMC] = 0;  // per-tick counters start the next tick at zero (sc_step_stats reads them
+                           // between sc_step_begin and sc_step_finish, i.e. before this kernel)
     counters[C_SUMC_HI] = 0;
     counters[C_MAXC] = 0;
     counters[C_NBIG] = 0;
@@ -715,7 +715,7 @@ __global__ void __launch_bounds__(kTileW)
   if (FUSED) {
     int cnext = -1, wsn = -1;
     const double xp = xn, yp = yn;  // as integrated: what a halo message carries (the receiver runs its own K1)
-    if (active) cnext = wall_and_cell(wn, xn, yn, wsn, counters, wrec_counter_next, wrec_next);
+    if (active) cnext = wall_and_cell(wn, xn, yn, wsn, counters, i, wrec_next);
     if (live) {
       cellS[i] = cnext;
       if (cnext >= 0) wslotS[i] = wsn;
