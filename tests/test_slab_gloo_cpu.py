@@ -47,12 +47,13 @@ def single_domain_oracle(n, ticks, vel, noise, margin):
     return p, v, pr, ids
 
 
-@pytest.mark.parametrize("nproc,noise,vel,margin", [(2, "counter", 30.0, 0.0), (3, "none", 10.0, 0.06)])
-def test_slabs_equal_single_domain(tmp_path, nproc, noise, vel, margin):
+@pytest.mark.parametrize("nproc,noise,vel,margin,n", [(2, "counter", 30.0, 0.0, 3000), (3, "none", 10.0, 0.06, 3000),
+                                                       (8, "counter", 30.0, 0.0, 24000)])
+def test_slabs_equal_single_domain(tmp_path, nproc, noise, vel, margin, n):
     # fast particles: many cross a cut (migration) and hit walls.  Without noise the particles start
     # away from the walls: the hard wall fix puts corner particles on the same point and the
     # reference's 0/0 (crate.py:174) then makes NaNs, which is not what this test is about.
-    n, ticks = 3000, 4
+    ticks = 4  # (8 ranks: the chain the driver's scaling run uses -- interior slabs with two neighbors each)
     got = run_workers(nproc, tmp_path / "slab.npz", "--backend", "oracle", "--particles", str(n), "--ticks", str(ticks),
                       "--vel", str(vel), "--noise", noise, "--margin", str(margin))
     p, v, pr, ids = single_domain_oracle(n, ticks, vel, noise, margin)
