@@ -719,3 +719,63 @@ def test_halo_buffer_overflow_is_reported(sc, tmp_path):
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert res.returncode != 0
     assert "a halo buffer was too small" in res.stderr
+
+
+# ------------------------------------------------------------------ randomised worlds
+@pytest.mark.parametrize("seed", range(10))
+def test_random_worlds_match_oracle(sc, seed):
+    """Worlds the two YAML scenes do not have: several fixed bodies with slanted segments inside the box, up
+    to two motored bodies that translate and spin, random coefficients and gravity direction,
+    particles all over the box (some inside bodies, some touching several segments at once).  Three ticks,
+    each against the oracle restarted from the GPU's previous state (see test_ticks_match_oracle)."""
+    from oracle.scene import OracleCrate
+    from oracle.tick import counter_noise_key, counter_noise_u01, remove_outside, tick_core
+    from oracle.world import World
+    rs = np.random.RandomState(1000 + seed)
+    n = int(rs.randint(1500, 6000))
+    d = float(np.sqrt(rs.uniform(4, 14) / (np.pi * n)))
+    cfg = sc.load_config("config/wave_machine.yaml")
+    wc = cfg.world_config
+    co = wc.coefficients
+    co.update(particle_radius=d / 2, dt=0.002 * d / 0.01 * rs.uniform(0.5, 2.0), max_particles=n,
+              collider_noise_level=float(rs.choice([0.0, 0.1, 0.3])), viscosity=float(rs.uniform(0, 12)),
+              pressure_amplifier=float(rs.uniform(5, 60)), ignored_pressure=float(rs.uniform(0, 0.6)),
+              surface_smoothing=float(rs.uniform(0, 150)), target_pressure=float(rs.uniform(-4, 2)),
+              wall_collision_decay=float(rs.uniform(0, 0.9)), gravity=[float(g) for g in rs.uniform(-9.8, 9.8, 2)])
+    wc.particle_sources = []
+    bodies = [wc.rigid_bodies[0]]  # the box
+    for _ in range(rs.randint(1, 4)):
+        k = int(rs.randint(1, 4))
+        pts = rs.rand(k + 1, 2) * 0.6 + 0.2
+        bodies.append({"fixed": {"name": "obstacle", "segments": [[pts[j].tolist(), pts[j + 1].tolist()] for j in range(k)]}})
+    for _ in range(rs.randint(0, 3)):
+        a, b, w0 = rs.uniform(-2, 2), rs.uniform(1, 9), rs.uniform(-3, 3)
+        bodies.append({"motored": {"name": "paddle", "segments": [[[0.0, 0.0], [0.0, -1.0]], [[0.0, 0.0], [-1.0, 0.0]]],
+                                   "velocity_func": f"lambda t: np.array([np.sin(t * {b}) * {a}, {a} * 0.3])",
+                                   "angular_velocity_func": f"lambda t: np.cos(t * {b}) * {w0}",
+                                   "scale": [float(rs.uniform(0.02, 0.2)), float(rs.uniform(0.1, 0.5))],
+                                   "rotation": float(rs.uniform(-180, 180)),
+                                   "position": [float(rs.uniform(0.2, 0.8)), float(rs.uniform(0.2, 0.8))]}})
+    wc.rigid_bodies = bodies
+    noise = "counter" if co["collider_noise_level"] > 0 else "none"
+    p = rs.rand(n, 2) * 0.98 + 0.01
+    v = (rs.rand(n, 2) - 0.5) * rs.choice([0.1, 3.0, 30.0])
+    crate = sc.Crate(wc, noise=noise, noise_seed=seed)
+    crate.particles, crate.particle_velocities = p, v
+    orc = OracleCrate(World(wc.rigid_bodies, [], dict(wc.coefficients)))
+    ids = np.arange(n)
+    for t in range(3):
+        crate.physics_tick()
+        for b in orc.rigid_bodies:
+            b.advance(orc.coef["dt"])
+        assert np.array_equal(crate.segments, orc.segments)
+        p, v, ids = remove_outside(p, v, orc.coef["particle_radius"], ids)
+        eta = None if noise == "none" else counter_noise_u01(ids, counter_noise_key(seed, t))
+        out = tick_core(p, v, orc.segments, orc.body_states(), orc.coef, eta_u01=eta)
+        gp, gv, gpr, gids = crate.engine.download()
+        keep = ~np.isnan(out["particles"]).any(axis=1)   # the reference keeps NaN particles, the library drops them
+        assert np.array_equal(gids, ids[keep])
+        np.testing.assert_allclose(gp, out["particles"][keep], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(gv, out["velocities"][keep], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(gpr, out["pressure"][keep], rtol=1e-9, atol=1e-12)
+        p, v, ids = gp, gv, gids
