@@ -410,12 +410,13 @@ void launch_pass_a_cap(sc_ctx* c) {
 template <int NOISE, bool ENUM, bool DENS>
 void launch_pass_a(sc_ctx* c, int kernel_id) {
   Bracket br(c, kernel_id);
-  // up to 8 workgroups per CU: all resident with the wide tile too; beyond that the narrow tile's
-  // higher occupancy wins (262,144 particles: 35.9 -> 32.2 us wide; 1,048,576: 78 us narrow, 82 us wide)
+  // up to 16 waves per CU: all resident with the wide tile too; beyond that the narrow tile's higher
+  // occupancy wins (measured with 128-wide tiles: 262,144 particles 35.9 -> 32.2 us wide; 1,048,576: 78 us
+  // narrow, 82 us wide)
   // (slabs size their grids by capacity; the live count a recent tick published is the better estimate of the work)
   const int published = *(volatile int*)(c->bigHintHost + 2);
   const int tiles = c->slab && published > 0 ? (published + kTileW - 1) / kTileW + 64 : tile_grid(c);
-  if (c->tile_choice ? c->tile_choice == 2 : tiles <= 8 * c->num_cus)
+  if (c->tile_choice ? c->tile_choice == 2 : tiles <= (8 * 128 / kTileW) * c->num_cus)
     launch_pass_a_cap<NOISE, ENUM, DENS, kTileCapAWide>(c);
   else
     launch_pass_a_cap<NOISE, ENUM, DENS, kTileCapA>(c);

@@ -30,11 +30,19 @@
 
 namespace sc {
 
-constexpr int kTileW = 128;      // particles (= threads) per workgroup
-// pass A tile, (x, y) records: 8 KiB when many workgroups share a CU (more waves in flight), 12 KiB when the
+// Tile geometry (measured, profiles/README.md): 256 particles per workgroup beat 128 by 2-3 % (less halo per
+// particle: 3 x (256 + 12) entries for 256 particles) and 64 lose 3-6 %.
+#ifndef SC_TILE_W
+#define SC_TILE_W 256
+#define SC_CAP_A 1024
+#define SC_CAP_AW 1536
+#define SC_CAP_B 960
+#endif
+constexpr int kTileW = SC_TILE_W;      // particles (= threads) per workgroup
+// pass A tile, (x, y) records: 16 KiB when many workgroups share a CU (more waves in flight), 24 KiB when the
 // whole grid is resident anyway (fewer tiles fall out of LDS); the launcher picks (measured: profiles/)
-constexpr int kTileCapA = 512, kTileCapAWide = 768;
-constexpr int kTileCapB = 480;   // pass B tile: (x, y, vx, vy, P, sx, sy, -) records, 30 KiB
+constexpr int kTileCapA = SC_CAP_A, kTileCapAWide = SC_CAP_AW;
+constexpr int kTileCapB = SC_CAP_B;   // pass B tile: (x, y), (sx, sy), P of the three ranges: 40 B per entry, 37.5 KiB
 constexpr int kSlotMax = 65535;  // lists are staged as u16 tile slots in pass A
 
 struct Tile {
@@ -430,8 +438,8 @@ __global__ void __launch_bounds__(kTileW)
 // apply_particles_velocity (:360-361).  Reads the sorted arrays (through the LDS tile), writes the
 // storage arrays in the same order: that is the next tick's input.
 // ------------------------------------------------------------------------------------------
-// The tile of pass B in LDS: (x, y), (sx, sy) and P of the three ranges -- 40 bytes per entry, 19 KiB,
-// so that eight workgroups share a CU (a 64-byte record with the velocities allowed five).  The
+// The tile of pass B in LDS: (x, y), (sx, sy) and P of the three ranges -- 40 bytes per entry, 37.5 KiB for
+// 256 particles, so that sixteen waves share a CU (a 64-byte record with the velocities allowed ten).  The
 // neighbors' start-of-tick velocities are only summed (crate.py:175, :319-323): they are staged into the
 // (x, y) array once the pair loop is done with it.
 struct PairSums {
