@@ -1219,7 +1219,7 @@ int sc_owned_count(sc_ctx* c, int64_t* n) {
   if (rc) return rc;
   if (!c->owned_out) HIPCHK(dalloc(&c->owned_out, 1));
   HIPCHK(hipMemsetAsync(c->owned_out, 0, sizeof(int), c->stream));
-  hipLaunchKernelGGL(k_owned_count, dim3(grid_for(launch_bound(c))), dim3(kBlock), 0, c->stream, c->w, c->counters, c->x[0],
+  hipLaunchKernelGGL(k_owned_count, dim3(grid_for(launch_bound(c))), dim3(kBlock), 0, c->stream, c->counters, c->x[0],
                      c->owned_out);
   int h = 0;
   HIPCHK(hipMemcpyAsync(&h, c->owned_out, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -76,11 +76,11 @@ enum Counter {
   C_SUMC = 4,   // sum of neighbor counts (low 32 bits)
   C_MAXC = 5,   // max neighbor count
   C_SUMC_HI = 6,
-  C_PACK_L = 7,  // halo records packed for the left / right neighbor this tick
-  C_PACK_R = 8,
+  C_SPARE7 = 7,  // (unused)
+  C_SPARE8 = 8,
   C_TICKET = 9,  // workgroups that have finished the current halo kernel (last one publishes / bumps)
   C_NBIG = 10,   // buckets above kSortThreshold listed this tick
-  C_WREC2 = 11,
+  C_SPARE11 = 11,
   C_COUNT = 12
 };
 

@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(kBlock) k_scan_fix(int* __restrict__ out, int 
 #pragma unroll
   for (int k = 0; k < kScanPerThread; ++k)
     if (base + k < n) out[base + k] += off;
-  if (blockIdx.x == nblocks - 1 && threadIdx.x == 0) {
+  if ((int)blockIdx.x == nblocks - 1 && threadIdx.x == 0) {
     int tot = off + blockSums[nblocks - 1];
     out[n] = tot;  // one-past-the-end entry: cellStart[ncells]
     if (total_out) *total_out = tot;
@@ -742,8 +742,8 @@ __global__ void __launch_bounds__(kBlock)
 
 // live particles in the storage arrays: everything but the dead ghost copies (x = +inf) a slab tick
 // leaves behind.  Across ranks every particle is stored live exactly once.
-__global__ void __launch_bounds__(kBlock) k_owned_count(World w, const int* __restrict__ counters,
-                                                        const double* __restrict__ x, int* __restrict__ out) {
+__global__ void __launch_bounds__(kBlock) k_owned_count(const int* __restrict__ counters, const double* __restrict__ x,
+                                                        int* __restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int own = 0;
   if (i < counters[C_NS]) {
