@@ -43,6 +43,7 @@ constexpr int kTileW = SC_TILE_W;      // particles (= threads) per workgroup
 // whole grid is resident anyway (fewer tiles fall out of LDS); the launcher picks (measured: profiles/)
 constexpr int kTileCapA = SC_CAP_A, kTileCapAWide = SC_CAP_AW;
 constexpr int kTileCapB = SC_CAP_B;   // pass B tile: (x, y), (sx, sy), P of the three ranges: 40 B per entry, 37.5 KiB
+constexpr int kDenseTile = kTileW * 43 / 10;  // 1100 entries for 256 particles (the usual tile has ~800)
 constexpr int kSlotMax = 65535;  // lists are staged as u16 tile slots in pass A
 
 struct Tile {
@@ -400,7 +401,9 @@ __global__ void __launch_bounds__(kTileW)
   tl.a2 = bounds[4];
   tl.n2 = bounds[5] - tl.a2;
   const int total = tl.n0 + tl.n1 + tl.n2;
-  const bool in_lds = total <= CAP;
+  // a tile that fits but is much denser than usual (some dense cell plus its sparse surroundings) is better off
+  // on the windowed path, which hands long fruitless walks to the whole wave (measured: profiles/README.md)
+  const bool in_lds = total <= min(CAP, kDenseTile);
 
   // 2. stage (x, y) of the three ranges; every load of the tile is in flight before the first LDS write
   if (in_lds) {
