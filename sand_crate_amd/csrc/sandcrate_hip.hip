@@ -95,7 +95,8 @@ struct sc_ctx {
   bool force_rank_big = false;
   int64_t cellAlloc = 0;
   double* wrec[2] = {nullptr, nullptr};  // wall records of even / odd ticks
-  int* nbr = nullptr;
+  int* nbr = nullptr;              // neighbor table of tiles beyond 65535 entries: -(sorted index + 1), 32 bit
+  unsigned short* nbr16 = nullptr;  // neighbor table, slot-major: tile slots, 16 bit
   unsigned char* cnt = nullptr;
   double *P = nullptr, *sx = nullptr, *sy = nullptr;
   int* counters = nullptr;
@@ -403,7 +404,7 @@ int tile_grid(const sc_ctx* c) { return (int)std::max<int64_t>(1, (launch_bound(
 template <int NOISE, bool ENUM, bool DENS, int CAP>
 void launch_pass_a_cap(sc_ctx* c) {
   hipLaunchKernelGGL((k_pass_a<NOISE, ENUM, DENS, CAP>), dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters,
-                     c->x[1], c->y[1], c->id[1], c->cellT, Buckets{c->cellStart, c->blockOff}, c->nbr, c->cnt, (int)c->cap, c->eta, c->offById,
+                     c->x[1], c->y[1], c->id[1], c->cellT, Buckets{c->cellStart, c->blockOff}, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta, c->offById,
                      c->P, c->sx, c->sy, c->tileBounds);
 }
 
@@ -427,7 +428,7 @@ void launch_pass_b(sc_ctx* c, const WallInputs& wn) {
   Bracket br(c, K_FORCE);
   const int cur = (int)(c->tick & 1), nxt = cur ^ 1;
   hipLaunchKernelGGL((k_pass_b<NOISE, FUSED>), dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters, c->x[1],
-                     c->y[1], c->vx[1], c->vy[1], c->id[1], c->wslotT, c->cellT, c->nbr, c->cnt, (int)c->cap, c->eta,
+                     c->y[1], c->vx[1], c->vy[1], c->id[1], c->wslotT, c->cellT, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta,
                      c->offById, c->P, c->sx, c->sy, c->wrec[cur], c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0],
                      c->tileBounds, c->bigHintDev, wn, c->cellS, c->wslotS, c->cellCount, c->wrec[nxt], c->haloL, c->haloR,
                      c->haloCap);
@@ -491,6 +492,7 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
   if (e == hipSuccess) e = dalloc(&c->wrec[0], 5 * n);
   if (e == hipSuccess) e = dalloc(&c->wrec[1], 5 * n);
   if (e == hipSuccess) e = dalloc(&c->nbr, (size_t)kMaxNbr * n);
+  if (e == hipSuccess) e = dalloc(&c->nbr16, (size_t)kMaxNbr * n);
   if (e == hipSuccess) e = dalloc(&c->cnt, n);
   if (e == hipSuccess) e = dalloc(&c->P, n);
   if (e == hipSuccess) e = dalloc(&c->sx, n);
@@ -519,7 +521,7 @@ int sc_destroy(sc_ctx* c) {
     (void)hipFree(c->id[s]);
   }
   void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->rankAcc, c->wrec[0], c->wrec[1],
-                  c->nbr, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
+                  c->nbr, c->nbr16, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
                   c->stage_xy, c->stage_vxy, c->owned_out};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -944,6 +946,7 @@ int sc_download_neighbors(sc_ctx* c, int64_t* ids, int32_t* counts, int64_t* nei
   std::vector<unsigned char> cnt(n);
   std::vector<double> hx(n), hy(n);
   std::vector<int> slot(n);
+  std::vector<unsigned short> slot16(n);
   const int64_t nblocks = (n + kTileW - 1) / kTileW;
   std::vector<int> tb(6 * std::max<int64_t>(nblocks, 1));
   if ((rc = fetch(c, tb.data(), c->tileBounds, 6 * nblocks * sizeof(int)))) return rc;
@@ -954,13 +957,16 @@ int sc_download_neighbors(sc_ctx* c, int64_t* ids, int32_t* counts, int64_t* nei
   if (neighbors)
     for (int64_t k = 0; k < n * kMaxNbr; ++k) neighbors[k] = -1;
   for (int s = 0; s < kMaxNbr && neighbors; ++s) {
-    if ((rc = fetch(c, slot.data(), c->nbr + (size_t)s * c->cap, n * sizeof(int)))) return rc;
+    if ((rc = fetch(c, slot.data(), c->nbr + (size_t)s * c->cap, n * sizeof(int))) ||
+        (rc = fetch(c, slot16.data(), c->nbr16 + (size_t)s * c->cap, n * sizeof(unsigned short))))
+      return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     for (int64_t k = 0; k < n; ++k) {
       if (s >= cnt[k]) continue;
       const int* b = tb.data() + 6 * (k / kTileW);  // the table holds tile slots of the particle's block
       const Tile tl{b[0], b[1] - b[0], b[2], b[3] - b[2], b[4], b[5] - b[4]};
-      neighbors[k * kMaxNbr + s] = id[entry_index(tl, slot[k])];
+      const bool big = tl.n0 + tl.n1 + tl.n2 > kSlotMax;  // then the 32-bit table holds -(index + 1)
+      neighbors[k * kMaxNbr + s] = id[entry_index(tl, big ? slot[k] : (int)slot16[k])];
     }
   }
   for (int64_t k = 0; k < n; ++k) {

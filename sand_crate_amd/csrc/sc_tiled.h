@@ -93,6 +93,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
                                             const bool live, const int idi, const int e0, const int b0, const int b1,
                                             const int e1, const int bm, const int em, const double* __restrict__ x,
                                             const double* __restrict__ y, int* __restrict__ nbr,
+                                            unsigned short* __restrict__ nbr16,
                                             unsigned char* __restrict__ cnt, const int cap,
                                             const double* __restrict__ eta, const int* __restrict__ offById,
                                             double* __restrict__ P, double* __restrict__ sx, double* __restrict__ sy) {
@@ -278,7 +279,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
     // lists were built by an earlier launch: bring them in (coalesced, slot-major)
     C = cnt[i];
     if (slots_fit)
-      for (int s = 0; s < C; ++s) list[s][t] = (unsigned short)nbr[(size_t)s * cap + i];
+      for (int s = 0; s < C; ++s) list[s][t] = nbr16[(size_t)s * cap + i];
   }
 
   // 4. pair math of pass A: populate_colliders (crate.py:161-175), pressures (:261-275), normals (:337-342)
@@ -329,7 +330,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
   // 5. lists out, slot-major: for a fixed slot consecutive threads write consecutive words
   if (ENUM && live) {
     if (slots_fit)
-      for (int s = 0; s < C; ++s) nbr[(size_t)s * cap + i] = (int)list[s][t];
+      for (int s = 0; s < C; ++s) nbr16[(size_t)s * cap + i] = list[s][t];
     cnt[i] = (unsigned char)C;
   }
 }
@@ -350,8 +351,8 @@ template <int NOISE, bool ENUM, bool DENS, int CAP>
 __global__ void __launch_bounds__(kTileW)
     k_pass_a(World w, const int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
              const int* __restrict__ id, const int* __restrict__ cell, Buckets bk,
-             int* __restrict__ nbr, unsigned char* __restrict__ cnt, int cap, const double* __restrict__ eta,
-             const int* __restrict__ offById, double* __restrict__ P, double* __restrict__ sx,
+             int* __restrict__ nbr, unsigned short* __restrict__ nbr16, unsigned char* __restrict__ cnt, int cap,
+             const double* __restrict__ eta, const int* __restrict__ offById, double* __restrict__ P, double* __restrict__ sx,
              double* __restrict__ sy, int* __restrict__ tileBounds) {
   __shared__ XY txy[CAP];
   __shared__ unsigned short list[kMaxNbr][kTileW + 2];  // tile slots of the neighbors, [slot][thread]
@@ -427,11 +428,11 @@ __global__ void __launch_bounds__(kTileW)
   if (ENUM && t < 6) tileBounds[6 * tile_id + t] = bounds[t];  // pass B stages the same three ranges
 
   if (in_lds)
-    pass_a_body<NOISE, ENUM, DENS, true, CAP>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr, cnt,
+    pass_a_body<NOISE, ENUM, DENS, true, CAP>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr, nbr16, cnt,
                                          cap, eta, offById, P, sx, sy);
   else
     pass_a_body<NOISE, ENUM, DENS, false, CAP>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr,
-                                          cnt, cap, eta, offById, P, sx, sy);
+                                          nbr16, cnt, cap, eta, offById, P, sx, sy);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -609,6 +610,7 @@ __global__ void __launch_bounds__(kTileW)
     k_pass_b(World w, int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
              const double* __restrict__ vx, const double* __restrict__ vy, const int* __restrict__ id,
              const int* __restrict__ wslot, const int* __restrict__ cell, const int* __restrict__ nbr,
+             const unsigned short* __restrict__ nbr16,
              const unsigned char* __restrict__ cnt, int cap, const double* __restrict__ eta,
              const int* __restrict__ offById, const double* __restrict__ P, const double* __restrict__ sx,
              const double* __restrict__ sy, const double* __restrict__ wrec, double* __restrict__ xo,
@@ -636,7 +638,7 @@ __global__ void __launch_bounds__(kTileW)
   const int idi = id[ic];
   int js[kMaxNbr];
 #pragma unroll
-  for (int s = 0; s < kMaxNbr; ++s) js[s] = nbr[(size_t)s * cap + ic];
+  for (int s = 0; s < kMaxNbr; ++s) js[s] = nbr16[(size_t)s * cap + ic];
   const int n = counters[C_NT];
   if (tile_id == 0 && t == 0) {
     counters[C_NS] = n;    // the storage arrays now hold the n live particles
@@ -660,6 +662,10 @@ __global__ void __launch_bounds__(kTileW)
   tl.a2 = tb4;
   tl.n2 = tb5 - tb4;
   const int total = tl.n0 + tl.n1 + tl.n2;
+  if (total > kSlotMax) {  // a block inside one gigantic bucket: its entries are indices in the 32-bit table
+#pragma unroll
+    for (int s = 0; s < kMaxNbr; ++s) js[s] = nbr[(size_t)s * cap + ic];
+  }
   const bool in_lds = total <= kTileCapB;
   const bool ghost = w.slab && (cpacked & kGhostBit);
   const int C = live ? Craw : 0;

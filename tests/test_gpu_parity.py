@@ -779,3 +779,53 @@ def test_random_worlds_match_oracle(sc, seed):
         np.testing.assert_allclose(gv, out["velocities"][keep], rtol=1e-9, atol=1e-10)
         np.testing.assert_allclose(gpr, out["pressure"][keep], rtol=1e-9, atol=1e-12)
         p, v, ids = gp, gv, gids
+
+
+# ------------------------------------------------------------------ one gigantic bucket (tiles beyond 65,535 entries)
+def _cluster_lists(pts, d):
+    """Neighbor lists of a cluster whose particles are ALL within d of each other and in one strip: to the
+    right in (x, index) order, then to the left descending, cut at 20 (collision_detector.py:85-93)."""
+    n = len(pts)
+    order = np.lexsort((np.arange(n), pts[:, 0]))
+    pos = np.empty(n, dtype=np.int64)
+    pos[order] = np.arange(n)
+    table = np.full((n, 20), -1, dtype=np.int64)
+    for i in range(n):
+        k = pos[i]
+        seq = list(order[k + 1:k + 21]) + list(order[max(k - 20, 0):k][::-1])
+        seq = seq[:20]
+        table[i, :len(seq)] = seq
+    return np.full(n, 20, dtype=np.int32), table
+
+
+def test_one_gigantic_bucket(sc):
+    """70,000 particles in a patch of one cell: the blocks inside it have tiles of more than 65,535 entries,
+    whose neighbor entries are sorted indices in the 32-bit table instead of 16-bit tile slots.  Sort, lists
+    (k_rank_big with 75,000 tasks, the direct search) and one full tick through that table."""
+    from oracle.neighbors import strip_sort
+    from oracle.scene import OracleCrate
+    from oracle.tick import tick_core
+    from oracle.world import World
+    rs = np.random.RandomState(12)
+    d, n = 0.05, 70000
+    pts = np.column_stack((0.5 + rs.rand(n) * d * 0.3, 0.5 + 0.01 + rs.rand(n) * d * 0.3))
+    rows, order, counts, table = sc.neighbor_search(pts, d)
+    ref_rows, ref_order = strip_sort(pts, d)
+    assert np.array_equal(rows, ref_rows) and np.array_equal(order, ref_order)
+    ref_counts, ref_table = _cluster_lists(pts, d)
+    assert np.array_equal(counts, ref_counts) and np.array_equal(table, ref_table)
+    wc = wave_world(sc, d, 0.0)
+    wc.coefficients["max_particles"] = n
+    crate = sc.Crate(wc, noise="none")
+    crate.particles, crate.particle_velocities = pts, np.zeros_like(pts)
+    crate.physics_tick()
+    orc = OracleCrate(World(wc.rigid_bodies, [], dict(wc.coefficients)))
+    for b in orc.rigid_bodies:
+        b.advance(orc.coef["dt"])
+    out = tick_core(pts, np.zeros_like(pts), orc.segments, orc.body_states(), orc.coef,
+                    neighbor_fn=lambda p, dd: _cluster_lists(p, dd))
+    gp, gv, gpr, gids = crate.engine.download()
+    assert np.array_equal(gids, np.arange(n))
+    np.testing.assert_allclose(gpr, out["pressure"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(gv, out["velocities"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(gp, out["particles"], rtol=1e-9, atol=1e-12)
