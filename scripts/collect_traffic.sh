@@ -8,6 +8,7 @@ set -e
 export TMPDIR=/tmp
 N=${1:-262144}
 OUT=gpurun_out/traffic
+rm -rf $OUT
 mkdir -p $OUT
 hipcc -O3 --offload-arch=gfx950 scripts/traffic_calib.hip -o /tmp/traffic_calib
 for c in FETCH_SIZE WRITE_SIZE; do
