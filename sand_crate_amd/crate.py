@@ -223,6 +223,8 @@ class Crate:
             raise RuntimeError("Crate.run needs noise='counter' or 'none'")
         if any(src.active_ticks > self.tick for src in self.particle_sources):
             raise RuntimeError("Crate.run cannot interleave particle sources; use physics_tick()")
+        if n_ticks <= 0:
+            return
         eng = self._engine
         # One library call per tick (sc_tick).  Nobody can edit coefficients inside run(), so every tick
         # also promises the next tick's inputs and its removal / wall pass rides on this tick's force

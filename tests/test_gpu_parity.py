@@ -829,3 +829,12 @@ def test_one_gigantic_bucket(sc):
     np.testing.assert_allclose(gpr, out["pressure"], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(gv, out["velocities"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(gp, out["particles"], rtol=1e-9, atol=1e-12)
+
+
+def test_run_zero_ticks_is_a_no_op(sc):
+    crate = sc.Crate(wave_world(sc, 0.02, 0.0), noise="none")
+    pts = np.random.RandomState(2).rand(100, 2) * 0.8 + 0.1
+    crate.particles, crate.particle_velocities = pts, np.zeros_like(pts)
+    seg = crate.segments.copy()
+    crate.run(0)
+    assert crate.tick == 0 and np.array_equal(crate.segments, seg) and np.array_equal(crate.particles, pts)
