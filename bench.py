@@ -3,18 +3,22 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--particles P_PER_GPU]
 
-Workload (BASELINE.json configs[1] at N=1): P = 262,144 synthetic
-uniformly seeded particles per GPU in the wave_machine.yaml world (its coefficients, both rigid
-bodies incl. the motored wall, no particle source), particle diameter d = sqrt(12 / (pi P_total))
-so that a particle has ~12 neighbors, dt scaled with d, collider_noise_level 0.1 from a
-counter-based device RNG.  A step is one `physics_tick` of all particles; state is resident in HBM
-before the timed region and nothing is read back inside it.
+Workload.  N=1: BASELINE.json configs[2], the largest single-GPU configuration --
+1,048,576 synthetic uniformly seeded particles in the wave_machine.yaml world (its coefficients, both rigid
+bodies incl. the motored wall, no particle source), particle diameter d = sqrt(12 / (pi P_total)) so that a
+particle has ~12 neighbors, dt scaled with d, collider_noise_level 0.1 from a counter-based device RNG.
+N=4 / N=8: configs[3] / configs[4] (4,194,304 / 16,777,216 particles in all, x-slabs, halo exchange per tick);
+N=2: 1,048,576 per GPU.  A step is one `physics_tick` of all particles; state is resident in HBM before the
+timed region and nothing is read back inside it.  The W+K-step measurement is repeated (--repeats, default 5)
+from the same initial state; `value` is the median repetition, all repetitions are listed.
 
 Prints ONE JSON line (rank 0).  Besides the contract keys it carries
-  roofline      the dominant kernel's algorithmic bytes / measured HIP-event time vs the 8 TB/s HBM peak
-  kernels       the same for every kernel of the tick
+  roofline      SURVEY.md M4's force-pair figure: 128 algorithmic bytes per particle / (pass A + pass B) measured
+                with HIP events on the kernels' stream, against the 8 TB/s HBM peak; pass A, pass B and the whole
+                tick as sub-objects; `fp64_issue`: the VALU issue roofline from committed SQ counters
+  kernels       time and algorithmic GB/s of every kernel of the tick
   cpu_baseline  the oracle's loop-structured tick (stands for the reference's NumPy path, which cannot
-                travel to the GPU box) timed on this host, one core, on a bounded sample
+                travel to the GPU box) timed on this host, one core, on a bounded sample (262,144 particles)
 """
 from __future__ import annotations
 
@@ -50,7 +54,9 @@ def measured_traffic(particles_per_gpu: int, kernel: str):
     separate runs, calibrated on a float64 copy: scripts/collect_traffic.sh -> profiles/r01_traffic_<N>.json).
     bench.py cannot collect hardware counters itself; it reports the committed measurement of the same
     workload, or None when there is none for this size."""
-    path = ROOT / "profiles" / f"r01_traffic_{particles_per_gpu}.json"
+    path = ROOT / "profiles" / f"r02_traffic_{particles_per_gpu}.json"
+    if not path.exists():
+        path = ROOT / "profiles" / f"r01_traffic_{particles_per_gpu}.json"
     if not path.exists():
         return None, None
     data = json.loads(path.read_text())
@@ -111,20 +117,50 @@ def cpu_baseline(sample_n: int):
     }
 
 
+# BASELINE.json configs: [2] 1M particles on one GPU (the largest single-GPU configuration, the N=1 workload),
+# [3] 4M over 4 GPUs, [4] 16M over 8 GPUs with the wave_machine motored wall; N=2 keeps [2]'s 1M per GPU.
+TOTAL_BY_GPUS = {1: 1048576, 2: 2097152, 4: 4194304, 8: 16777216}
+
+
+def fp64_issue(particles_per_gpu: int, kernels: dict):
+    """VALU issue roofline of the force pair from the committed SQ counters (profiles/r02_sq_<N>.json, written by
+    scripts/collect_sq.sh on the same workload): wave-instructions issued per launch against what 1,024 SIMDs can
+    issue in the measured kernel time.  None when no counter file exists for this size."""
+    path = ROOT / "profiles" / f"r02_sq_{particles_per_gpu}.json"
+    if not path.exists():
+        return None
+    data = json.loads(path.read_text())
+    out = {"source": f"profiles/{path.name}: {data.get('source', '')}", "simds": 1024, "clock_GHz": 2.4}
+    for name in ("neighbors_density", "force_integrate"):
+        k, t = data["kernels"].get(name), kernels.get(name)
+        if not k or not t:
+            continue
+        busy_cycles = 4.0 * k["SQ_ACTIVE_INST_VALU"] / 1024  # quad-cycles summed over SIMDs -> cycles per SIMD
+        out[name] = {"valu_wave_insts_per_particle": round(k["SQ_INSTS_VALU"] / particles_per_gpu, 2),
+                     "valu_busy_us_at_2.4GHz": round(busy_cycles / 2400.0, 2),
+                     "frac_of_kernel_time": round(busy_cycles / 2400.0 / t["avg_us"], 3)}
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--particles", type=int, default=262144, help="particles per GPU")
+    ap.add_argument("--particles", type=int, default=0,
+                    help="particles per GPU (default: BASELINE.json's configuration for this GPU count: 1,048,576 per GPU "
+                         "at 1, 2 and 4 GPUs, 2,097,152 per GPU -- 16,777,216 in all -- at 8)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the W+K-step measurement is repeated this many times from the same initial state; `value` is the "
+                         "median repetition (each repetition times exactly K steps)")
     ap.add_argument("--cpu-sample", type=int, default=262144,
-                    help="particles in the CPU baseline tick (0 = skip); the default is one tick of the full workload, ~12 s")
+                    help="particles in the CPU baseline tick (0 = skip); 262,144 is one tick of ~13 s")
     ap.add_argument("--noise", default="counter", choices=["counter", "none"])
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: every rank uses cuda:0 and the gloo backend (halo staged through the "
                          "host), to exercise the N > 1 code path on a one-GPU box; the numbers mean nothing")
     ap.add_argument("--no-kernel-events", action="store_true",
-                    help="do not bracket kernels with HIP events in the timed region (no roofline in the output)")
+                    help="no replay with HIP events around the kernels (no roofline in the output)")
     args = ap.parse_args()
 
     import torch
@@ -140,7 +176,8 @@ def main() -> None:
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    n_total = args.particles * world
+    n_total = args.particles * world if args.particles > 0 else TOTAL_BY_GPUS.get(world, 1048576 * world)
+    per_gpu = n_total // world
 
     wc, d = world_for(n_total)
     p, v = synthetic_state(n_total)
@@ -156,11 +193,17 @@ def main() -> None:
         def barrier():
             return None
 
+    slab_sim = []
+
     def make_sim():
         import copy
         w = copy.deepcopy(wc)
-        if world > 1:
-            return SlabCrate(w, p, v, device=local_rank, noise=args.noise, noise_seed=1)
+        if world > 1:  # one communicator and one set of halo buffers for the whole run; the state is uploaded again
+            if slab_sim:
+                slab_sim[0].reload(p, v)
+            else:
+                slab_sim.append(SlabCrate(w, p, v, device=local_rank, noise=args.noise, noise_seed=1))
+            return slab_sim[0]
         s = sc.Crate(w, device=local_rank, noise=args.noise, noise_seed=1, capacity=n_total + 1024)
         s.particles = p
         s.particle_velocities = v
@@ -175,11 +218,6 @@ def main() -> None:
     primer.synchronize()
     del primer
 
-    sim = make_sim()
-
-    def run(k):
-        sim.run(k)
-
     device_flags = []
 
     def settle(s):
@@ -191,50 +229,71 @@ def main() -> None:
         except NativeError as err:
             device_flags.append(str(err))
 
-    run(args.warmup)
-    settle(sim)
-    torch.cuda.synchronize()
+    # ---- timed region, repeated: W untimed warm-up steps, then exactly K steps bracketed by barrier +
+    # synchronize on both sides, no per-kernel events; every repetition starts from the same initial state.
+    def max_over_ranks(x: float) -> float:
+        if world == 1:
+            return x
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    # ---- timed region: exactly K steps, barrier + synchronize on both sides, no per-kernel events
-    eng = sim.engine
-    barrier()
-    torch.cuda.synchronize()
-    settle(sim)
-    t0 = time.perf_counter()
-    run(args.steps)
-    settle(sim)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    reps = []
+    sim = None
+    for _ in range(max(1, args.repeats)):
+        sim = None  # release the previous repetition's device memory before allocating again
+        sim = make_sim()
+        sim.run(args.warmup)
+        settle(sim)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        settle(sim)
+        t0 = time.perf_counter()
+        sim.run(args.steps)
+        settle(sim)
+        torch.cuda.synchronize()
+        barrier()
+        reps.append(max_over_ranks(time.perf_counter() - t0))
+    order = sorted(reps)
+    elapsed = order[(len(order) - 1) // 2]  # the median repetition (lower middle for an even count)
+    transport = getattr(sim, "transport", None)
 
-    # ---- kernel durations: the same ticks replayed from the same initial state, every launch
-    # bracketed by two HIP events on the stream the kernels run on.  Kept out of the timed region because the 14 event records per tick
-    # cost ~15 % wall time at this size (measured); kernel durations themselves are unaffected.
+    # ---- kernel durations: the same ticks replayed from the same initial state, every launch bracketed by two
+    # HIP events on the stream the kernels run on.  Kept out of the timed region because the event records cost
+    # wall time; kernel durations themselves are unaffected.
     timing = {}
     n_live = sim.particle_count if world == 1 else sim.global_particle_count()
     if not args.no_kernel_events:
+        sim = None
         sim = make_sim()  # same initial state, same ticks as the timed region
         eng = sim.engine
-        run(args.warmup)
+        sim.run(args.warmup)
         settle(sim)
         eng.reset_timing()
         eng.enable_timing(True)
-        run(args.steps)
+        sim.run(args.steps)
         settle(sim)
         eng.enable_timing(False)
         timing = eng.timing()
 
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    base = {"metric": "particle-steps/sec", "value": n_total * args.steps / elapsed, "unit": "particle-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "repeats": {"count": len(reps), "ms_per_step": [round(1000.0 * r / args.steps, 5) for r in reps],
+                        "min": round(1000.0 * order[0] / args.steps, 5), "max": round(1000.0 * order[-1] / args.steps, 5),
+                        "value_is": "median repetition"},
+            "config": {"workload": f"{per_gpu} synthetic uniform particles per GPU ({n_total} total), "
+                                   f"wave_machine.yaml world incl. the motored wall, d=sqrt(12/(pi*P)) (~12 neighbors), "
+                                   f"collider noise 0.1 ({args.noise} RNG), ticks {args.warmup}..{args.warmup + args.steps - 1}",
+                       "particles_per_gpu": per_gpu, "particles_total": n_total, "live_after_run": int(n_live),
+                       "parallelism": "single GPU" if world == 1 else f"{world} x-slabs, halo exchange per tick",
+                       "transport": transport}}
     if rank == 0 and args.no_kernel_events:
-        print(json.dumps({"metric": "particle-steps/sec", "value": n_total * args.steps / elapsed,
-                          "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": 1000.0 * elapsed / args.steps, "note": "no per-kernel events"}))
+        base["note"] = "no per-kernel events"
+        print(json.dumps(base))
     elif rank == 0:
-        per_gpu = args.particles
         kernels = {}
         for name, (ms, launches) in timing.items():
             if launches == 0:
@@ -243,46 +302,40 @@ def main() -> None:
             gbps = ALGO_BYTES.get(name, 0) * per_gpu / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
             kernels[name] = {"avg_us": round(avg_us, 3), "launches": launches, "us_per_tick": round(1000.0 * ms / args.steps, 3),
                              "algo_bytes_per_particle": ALGO_BYTES.get(name, 0), "achieved_GBps": round(gbps, 1)}
-        # BASELINE.json's metric is "% HBM-BW roofline in force kernel": the roofline object describes the fused
-        # force + integrate kernel (pass B).  Pass A takes about the same time per tick; it, the pair and the
-        # whole tick are reported next to it.
-        dom = "force_integrate"
+        # BASELINE.json's metric is "% HBM-BW roofline in force kernel"; SURVEY.md section 8d (M4) defines it over
+        # the two force kernels together: 128 B per particle-step / (t_passA + t_passB).  That pair is the headline
+        # `frac`; pass A, pass B and the whole tick are reported next to it.
         tick_us = sum(k["us_per_tick"] for k in kernels.values())  # kernels that run once in a while count by their share
         pass_a = "neighbors_density" if "neighbors_density" in kernels else "density"
-        force_us = kernels[pass_a]["avg_us"] + kernels["force_integrate"]["avg_us"]
-        traffic, traffic_src = measured_traffic(per_gpu, dom)
+        dom = "force_integrate"
+        force_us = kernels[pass_a]["avg_us"] + kernels[dom]["avg_us"]
+        pair_gbps = FORCE_BYTES * per_gpu / (force_us * 1e-6) / 1e9
+        traffic_a, traffic_src = measured_traffic(per_gpu, pass_a)
+        traffic_b, _ = measured_traffic(per_gpu, dom)
+        traffic = traffic_a + traffic_b if traffic_a is not None and traffic_b is not None else None
+
+        def sub(name):
+            return {"kernel": name, "bytes_per_particle": ALGO_BYTES[name], "us": kernels[name]["avg_us"],
+                    "achieved_GBps": kernels[name]["achieved_GBps"],
+                    "frac": round(kernels[name]["achieved_GBps"] / HBM_PEAK_GBPS, 5),
+                    "traffic": measured_traffic(per_gpu, name)[0]}
+
         roofline = {
-            "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS, 5), "traffic": traffic,
-            "traffic_source": traffic_src,
-            "note": "this path is not HBM bound on MI355X: at this size kernels are chains of cold-L2 misses plus "
-                    "fp64 VALU issue, from ~1M particles on fp64 VALU issue alone (DESIGN.md section 6)",
-            "measured_over": f"a replay of the same {args.warmup}+{args.steps} ticks from the same initial state right after the timed region, HIP events around every launch",
-            "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * per_gpu,
-            "avg_launch_us": kernels[dom]["avg_us"],
-            "pass_a": {"kernel": pass_a, "bytes_per_particle": ALGO_BYTES[pass_a], "us": kernels[pass_a]["avg_us"],
-                       "achieved_GBps": kernels[pass_a]["achieved_GBps"],
-                       "frac": round(kernels[pass_a]["achieved_GBps"] / HBM_PEAK_GBPS, 5)},
-            "force_pair": {"kernels": f"{pass_a} + force_integrate", "bytes_per_particle": FORCE_BYTES,
-                           "us": round(force_us, 3),
-                           "achieved_GBps": round(FORCE_BYTES * per_gpu / (force_us * 1e-6) / 1e9, 1),
-                           "frac": round(FORCE_BYTES * per_gpu / (force_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5)},
+            "bound": "hbm", "kernel": f"{pass_a} + {dom} (the force pair of SURVEY.md M4)",
+            "achieved": round(pair_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(pair_gbps / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": FORCE_BYTES * per_gpu, "avg_launch_us": round(force_us, 3),
+            "measured_over": f"a replay of the same {args.warmup}+{args.steps} ticks from the same initial state right "
+                             f"after the timed region, HIP events around every launch on the kernels' own stream",
+            "pass_a": sub(pass_a), "pass_b": sub(dom),
             "whole_tick": {"bytes_per_particle": TICK_BYTES, "kernel_us_sum": round(tick_us, 3),
                            "achieved_GBps": round(TICK_BYTES * per_gpu / (tick_us * 1e-6) / 1e9, 1),
                            "frac": round(TICK_BYTES * per_gpu / (tick_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5)},
+            "fp64_issue": fp64_issue(per_gpu, kernels),
         }
-        line = {
-            "metric": "particle-steps/sec", "value": n_total * args.steps / elapsed, "unit": "particle-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.particles} synthetic uniform particles per GPU ({n_total} total), "
-                                   f"wave_machine.yaml world, d=sqrt(12/(pi*P)) (~12 neighbors), "
-                                   f"collider noise 0.1 ({args.noise} RNG)",
-                       "particles_per_gpu": args.particles, "particles_total": n_total, "live_after_run": int(n_live),
-                       "parallelism": "single GPU" if world == 1 else f"{world} x-slabs, halo exchange per tick"},
-            "roofline": roofline, "kernels": kernels,
-        }
+        line = dict(base)
+        line["roofline"] = roofline
+        line["kernels"] = kernels
         if device_flags:
             line["device_flags"] = sorted(set(device_flags))
         if world == 1 and args.cpu_sample > 0:

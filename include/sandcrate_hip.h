@@ -218,12 +218,15 @@ int sc_halo_unpack(sc_ctx* ctx, const double* dev_from_left, const double* dev_f
  * calls above will do; sand_crate_amd.slab falls back to torch.distributed P2P ops).  librccl is dlopen()ed
  * on first use -- the copy already loaded in the process if any, else `rccl_path`, else the default search
  * path -- so the library itself has no link-time dependency on it.
+ *   sc_comm_available  0 when librccl can be loaded in this process: every rank checks (and the ranks agree on
+ *                      the answer) BEFORE any of them enters the collective sc_comm_init
  *   sc_comm_unique_id  rank 0: 128 bytes to hand to every rank (ncclGetUniqueId)
  *   sc_comm_init       collective over the `world` contexts of the slab chain (ncclCommInitRank); rank = slab index
  *   sc_halo_exchange   on the context's stream, one group: send `send_left` to / receive `recv_left` from
  *                      rank `left_rank`, the same on the right; a negative rank means no neighbor on that side.
  *                      All four buffers are (capacity_records + 1) * 5 doubles of device memory.
  * A failing RCCL call returns SC_ERR_HIP with RCCL's message in sc_last_error(). */
+int sc_comm_available(const char* rccl_path);
 int sc_comm_unique_id(const char* rccl_path, void* id_128_bytes);
 int sc_comm_init(sc_ctx* ctx, const char* rccl_path, const void* id_128_bytes, int32_t rank, int32_t world);
 int sc_comm_destroy(sc_ctx* ctx);

@@ -191,9 +191,7 @@ class Crate:
         else:
             eng.step(1)
             self._count_known = False
-        for body in self.rigid_bodies:  # crate.py:311-314: gravity accelerates free bodies
-            if body.moves and not body.driven:
-                body.center_velocity = body.center_velocity + self.dt * self.gravity
+        self._accelerate_free_bodies()
         self._cache = None
         self.tick += 1
         if self._hud_kernels:  # the HUD's phase split (timer.py:37-48), from HIP events; synchronises the tick
@@ -234,6 +232,7 @@ class Crate:
         now = self._pack_tick_inputs()
         for k in range(n_ticks):
             nxt = None
+            self._accelerate_free_bodies()  # this tick's gravity step on free bodies precedes the next tick's motion
             if k + 1 < n_ticks:
                 for body in self.rigid_bodies:
                     body.apply_velocity(self.dt)
@@ -243,6 +242,14 @@ class Crate:
             now = nxt
         self._cache = None
         self._count_known = False
+
+    def _accelerate_free_bodies(self) -> None:
+        """crate.py:311-314: gravity accelerates bodies that are neither fixed nor motored.  (Each body owns its
+        velocity here; the reference's default `center_velocity` is one array shared by all bodies,
+        rigid_body.py:21 -- INTEGRATION.md, deviations.)"""
+        for body in self.rigid_bodies:
+            if body.moves and not body.driven:
+                body.center_velocity = body.center_velocity + self.dt * self.gravity
 
     def synchronize(self) -> None:
         self._engine.synchronize()

@@ -130,6 +130,8 @@ struct sc_ctx {
   long long own_lo = 0, own_hi = 0;
   int halo = 0, has_left = 0, has_right = 0;
   int* stage_ids = nullptr;
+  std::vector<int> ids_host;
+  int64_t stats_live = -1;  // live count read by sc_step_stats inside the current tick, or -1
   int* owned_out = nullptr;
   World w{};
   // sc_set_next_inputs: the promised inputs of the tick after the current one
@@ -222,9 +224,11 @@ int ensure_stage(sc_ctx* c, int64_t n) {
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->stage_xy) (void)hipFree(c->stage_xy);
   if (c->stage_vxy) (void)hipFree(c->stage_vxy);
+  if (c->stage_ids) (void)hipFree(c->stage_ids);
   int64_t m = n + n / 2 + 256;
   HIPCHK(dalloc(&c->stage_xy, 2 * m));
   HIPCHK(dalloc(&c->stage_vxy, 2 * m));
+  HIPCHK(dalloc(&c->stage_ids, m));
   c->stageAlloc = m;
   return SC_OK;
 }
@@ -297,6 +301,7 @@ int build_world(sc_ctx* c, World& w, const sc_params& p, int nseg, const Seg* se
   }
   w.inv_d = 1.0 / w.d;
   w.eta_scale = (w.d * w.level) * (1.0 / 4294967296.0);
+  w.eta_half = (w.d * w.level) * 0.5;
   w.nseg = nseg;
   w.nbody = nbody;
   std::memcpy(w.seg, seg, sizeof w.seg);
@@ -373,16 +378,17 @@ int put_particles(sc_ctx* c, const double* xy, const double* vxy, int64_t n, boo
     HIPCHK(hipMemcpyAsync(c->stage_vxy, vxy, 2 * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     int* dev_ids = nullptr;
     int64_t max_id = -1;
-    std::vector<int> ids32;
+    std::vector<int>& ids32 = c->ids_host;  // outlives the asynchronous copy below
     if (ids) {
+      HIPCHK(hipStreamSynchronize(c->stream));  // an earlier copy out of ids_host has finished
       ids32.resize(n);
       for (int64_t k = 0; k < n; ++k) {
         if (ids[k] < 0 || ids[k] > std::numeric_limits<int>::max() - 1) return fail(SC_ERR_ARG, "particle id out of range");
         ids32[k] = (int)ids[k];
         max_id = std::max<int64_t>(max_id, ids[k]);
       }
-      dev_ids = reinterpret_cast<int*>(c->stage_vxy + 2 * n);  // the staging buffer has 50 % headroom
-      HIPCHK(hipMemcpy(dev_ids, ids32.data(), n * sizeof(int), hipMemcpyHostToDevice));
+      dev_ids = c->stage_ids;  // its own allocation of stageAlloc entries (ensure_stage)
+      HIPCHK(hipMemcpyAsync(dev_ids, ids32.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
       c->next_id = std::max<int64_t>(c->next_id, max_id + 1 - n);
     }
     Bracket br(c, K_APPEND);
@@ -522,7 +528,7 @@ int sc_destroy(sc_ctx* c) {
   }
   void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->rankAcc, c->wrec[0], c->wrec[1],
                   c->nbr, c->nbr16, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
-                  c->stage_xy, c->stage_vxy, c->owned_out};
+                  c->stage_xy, c->stage_vxy, c->stage_ids, c->owned_out};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& v : {c->ev_used, c->ev_free})
@@ -709,6 +715,7 @@ int sc_step_begin(sc_ctx* c) {
   HIPCHK(hipGetLastError());
   c->in_step = true;
   c->etaPairs = -1;
+  c->stats_live = -1;
   return SC_OK;
 }
 
@@ -719,6 +726,7 @@ int sc_step_stats(sc_ctx* c, sc_stats* out) {
   int h[C_COUNT];
   int rc = read_counters(c, h);
   if (rc) return rc;
+  c->stats_live = h[C_NT];
   out->particles = h[C_NT];
   out->neighbor_slots = (int64_t)(uint32_t)h[C_SUMC] + ((int64_t)h[C_SUMC_HI] << 32);
   out->max_neighbors = h[C_MAXC];
@@ -787,6 +795,11 @@ int sc_step_finish(sc_ctx* c) {
   c->in_step = false;
   c->tick += 1;
   c->normals_valid = 1;
+  // pass B stores exactly the live particles of this tick: a count the host has read inside the tick
+  // (sc_step_stats) brings the host-side bound back down, so that a long run of emit / remove / emit
+  // without downloads does not accumulate `upper` as everything ever emitted
+  if (c->stats_live >= 0 && !c->slab) c->upper = c->stats_live;
+  c->stats_live = -1;
   return SC_OK;
 }
 
@@ -1155,6 +1168,11 @@ int sc_halo_unpack(sc_ctx* c, const double* from_left, const double* from_right,
     int rc_ = (expr);                                                                       \
     if (rc_ != 0) return fail(SC_ERR_HIP, "RCCL: %s failed: %s", #expr, rccl_error(rc_)); \
   } while (0)
+
+int sc_comm_available(const char* rccl_path) {
+  if (rccl_load(rccl_path)) return fail(SC_ERR_HIP, "%s", rccl_api().error.c_str());
+  return SC_OK;
+}
 
 int sc_comm_unique_id(const char* rccl_path, void* id) {
   if (!id) return fail(SC_ERR_ARG, "null argument");

@@ -32,6 +32,7 @@ struct World {
   double dt, r, d, decay, pamp, ignored, level, visc, ss, tp, gx, gy;
   double inv_d;      // 1/d, for the float-tolerance math only (never for a decision)
   double eta_scale;  // d * collider_noise_level / 2^32, for the counter noise
+  double eta_half;   // 2^31 * eta_scale = d * collider_noise_level / 2
   // decision thresholds derived on the host, see sc_host.cpp: make_world()
   double t_nbr;      // largest s with sqrt(s) <= d          (collision_detector.py:78-79)
   double t_wall;     // largest s with sqrt(s) <= r * 1.2    (crate.py:229)

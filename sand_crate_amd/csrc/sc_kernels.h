@@ -623,6 +623,26 @@ __device__ __forceinline__ void collider_noise(const World& w, uint64_t z, int s
   }
 }
 
+// r = p_i - (p_j + eta) of crate.py:167-171 from the difference (dx, dy) = p_i - p_j.  Nothing here feeds a decision.
+// Counter mode: eta = (hi32 - 2^31) * eta_scale, folded into one convert and one fused multiply-add per
+// component: r = (dx + 2^31 eta_scale) - u32 * eta_scale.
+template <int NOISE>
+__device__ __forceinline__ void pair_offset(const World& w, uint64_t z, int slot, const double* __restrict__ eta, int off,
+                                            double dx, double dy, double& rx, double& ry) {
+  if (NOISE == SC_NOISE_COUNTER) {
+    z ^= z >> 32;
+    z *= kMix;
+    z ^= z >> 32;
+    rx = fma((double)(uint32_t)(z >> 32), -w.eta_scale, dx + w.eta_half);
+    ry = fma((double)(uint32_t)z, -w.eta_scale, dy + w.eta_half);
+  } else {
+    double ex, ey;
+    collider_noise<NOISE>(w, z, slot, eta, off, ex, ey);
+    rx = dx - ex;
+    ry = dy - ey;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Halo exchange for x-slabs (no reference counterpart).  Records are
 // (x, y, vx, vy, id) as five doubles; record 0 of a buffer is a header whose first 32-bit word is the

@@ -32,6 +32,9 @@ namespace sc {
 
 // Tile geometry (measured, profiles/README.md): 256 particles per workgroup beat 128 by 2-3 % (less halo per
 // particle: 3 x (256 + 12) entries for 256 particles) and 64 lose 3-6 %.
+#ifndef SC_SCAN_BATCH
+#define SC_SCAN_BATCH 2
+#endif
 #ifndef SC_TILE_W
 #define SC_TILE_W 256
 #define SC_CAP_A 1024
@@ -113,7 +116,11 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
   const int self = i - tl.a0;
   XY pi = {0.0, 0.0};
   if (live) pi = load_xy(self);
+#ifdef SC_ABL_A_NOENUM
+  if (false) {
+#else
   if (ENUM) {
+#endif
     if (slots_fit && (LDS ? live : true)) {
       const double xi = pi.x, yi = pi.y;
       // One scan: `count` candidates from tile slot `first`, walking by `step`, examined one by one in
@@ -130,23 +137,36 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       //   by the whole wave, 64 candidates per step, hits ranked by lane = scan order.  Every
       //   particle still sees its candidates in the reference's order, so the lists are the same.
       constexpr int kHalf = CAP / 2, kSerial = 32;
+      const double dstop = w.d * (1.0 + 0x1p-20);
       auto scan = [&](bool want, int first, int count, int step, auto window) {
         if constexpr (LDS) {
-          if (!want) return;
-          bool done = false;
-          for (int v = 0; v < count && !done; ++v) {
-            const int slot = first + v * step;
-            const XY q = txy[slot];
-            const int verdict = window(q.x, xi);
-            if (verdict == 0) {
-              done = true;
-            } else if (verdict == 2) {
-              const double dx = q.x - xi, dy = q.y - yi;
-              if (dx * dx + dy * dy <= w.t_nbr) {  // norm(p_j - p_i) <= d (collision_detector.py:78-79)
-                list[C][t] = (unsigned short)slot;
-                if (++C == kMaxNbr) done = true;   // trim (:91-93)
+          // kBatch candidates per iteration: their LDS reads are issued together (one latency per batch
+          // instead of one per candidate) and their tests are independent instruction streams.  The loop
+          // stops on a conservative test of dx (never before the reference's window ends: a candidate
+          // beyond d (1 + 2^-20) in x can neither be in the window nor within d); a hit is decided
+          // exactly -- the reference's window expression AND the distance predicate.
+          constexpr int kBatch = SC_SCAN_BATCH;
+          bool done = !want;
+          for (int v = 0; v < count && !done; v += kBatch) {
+            XY q[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) q[k] = txy[first + (v + k < count ? v + k : v) * step];
+            bool hit[kBatch];
+            bool stop = false;
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+              const double dx = q[k].x - xi, dy = q[k].y - yi;
+              stop |= step > 0 ? dx > dstop : dx < -dstop;
+              hit[k] = dx * dx + dy * dy <= w.t_nbr && window(q[k].x, xi) == 2 && v + k < count;
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+              if (hit[k] && C < kMaxNbr) {  // trim (:91-93)
+                list[C][t] = (unsigned short)(first + (v + k) * step);
+                ++C;
               }
             }
+            done = stop || C == kMaxNbr;
           }
         } else {
           const int lane = t & 63, wave0 = t & ~63;
@@ -282,16 +302,31 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       for (int s = 0; s < C; ++s) list[s][t] = nbr16[(size_t)s * cap + i];
   }
 
+#ifdef SC_ABL_A_NOENUM
+  C = 0;
+#endif
   // 4. pair math of pass A: populate_colliders (crate.py:161-175), pressures (:261-275), normals (:337-342)
   if (DENS && live) {
     // nothing here feeds a decision: multiply-adds may fuse (the file is compiled with -ffp-contract=off)
 #pragma clang fp contract(fast)
-    double sumw = 0, ax = 0, ay = 0;
+    // Per pair (crate.py:167-174, :270, :342), arranged for the fewest float64 instructions:
+    //   r = p_i - (p_j + eta),  |r|^2 = s2,  1/|r| = rinv,  c = clip(|r| / d, 0, 1)  (|r| >= 0: only the upper clip acts)
+    //   overlap w = 1 - c  ->  sum_w = C - sum c;   (1 - w) w n = c (1 - c) rinv r
+    // A zero distance gives rinv = NaN: max(NaN, 0) = 0 makes c = 0, overlap 1 -- what the reference computes from
+    // dist = 0 (crate.py:270) -- while g = NaN reaches ax / ay like the reference's 0/0 (crate.py:174).
+    double sumc = 0, ax = 0, ay = 0;
     const int off = (NOISE == SC_NOISE_HOST) ? offById[idi] : 0;
     uint64_t z = noise_base(w.noise_key, idi);
     constexpr int kFetch = LDS ? 1 : 4;  // global-memory tiles: four neighbors per round trip
     XY qq[kFetch];
-    for (int s = 0; s < C; ++s) {
+#if defined(SC_ABL_A_NOPAIRS)
+    const int Cloop = 0;
+#elif defined(SC_ABL_CAPC)
+    const int Cloop = min(C, SC_ABL_CAPC);
+#else
+    const int Cloop = C;
+#endif
+    for (int s = 0; s < Cloop; ++s) {
       if (s % kFetch == 0) {
 #pragma unroll
         for (int k = 0; k < kFetch; ++k) {
@@ -308,21 +343,18 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
 #pragma unroll
       for (int k = 1; k < kFetch; ++k)
         if (s % kFetch == k) q = qq[k];
-      double ex, ey;
-      collider_noise<NOISE>(w, z, s, eta, off, ex, ey);
+      double rx, ry;
+      pair_offset<NOISE>(w, z, s, eta, off, pi.x - q.x, pi.y - q.y, rx, ry);
       z += kGold;
-      const double rx = pi.x - (q.x + ex), ry = pi.y - (q.y + ey);  // crate.py:167-171
       const double s2 = rx * rx + ry * ry;
       const double rinv = rsqrt_nr(s2);
-      const double dist = s2 * rinv;
-      const double nx = rx * rinv, ny = ry * rinv;   // crate.py:174
-      const double ov = 1 - clip01(dist * w.inv_d);  // crate.py:270
-      sumw += ov;
-      const double tt = (1 - ov) * ov;               // crate.py:342
-      ax += tt * nx;
-      ay += tt * ny;
+      const double c = fmin(fmax(s2 * rinv * w.inv_d, 0.0), 1.0);  // crate.py:270: clip(dist / d, 0, 1)
+      sumc += c;
+      const double g = c * (1 - c) * rinv;             // crate.py:342 with n = r / dist (:174)
+      ax += g * rx;
+      ay += g * ry;
     }
-    P[i] = C ? fmax(0.0, sumw - w.ignored) : 0.0;  // crate.py:265-273
+    P[i] = C ? fmax(((double)C - sumc) - w.ignored, 0.0) : 0.0;  // crate.py:265-273
     sx[i] = ax;
     sy[i] = ay;
   }
@@ -447,11 +479,16 @@ __global__ void __launch_bounds__(kTileW)
 // neighbors' start-of-tick velocities are only summed (crate.py:175, :319-323): they are staged into the
 // (x, y) array once the pair loop is done with it.
 struct PairSums {
-  double tx, ty, qx, qy;
+  double tx, ty;  // the velocity change of apply_tension + the particle part of apply_pressure, dt included
 };
 
 // Phase 3a of pass B for one particle: the pair loop.  LDS: where the tile is (compile time, see the
 // header).  js[] are neighbor-table entries (tile slots, or -(index+1)); `self` is the particle's own slot.
+//   tension  (crate.py:347-353): v += dt sum_j [ss ((s_i - s_j) . n_ij) + (P_i + P_j - 2 tp)] n_ij
+//   pressure (crate.py:301-306): v += dt pamp sum_j (P_i + P_j) n_ij
+// Neither reads a velocity, and gravity in between is a constant, so the two sums are taken together:
+//   dv = sum_j w_j n_ij,   w_j = (dt ss) (ds . n_ij) + (P_i + P_j) dt (1 + pamp) - 2 tp dt,   n_ij = r rinv
+// (one multiply-add chain per pair instead of two accumulations; rounding differs at 1e-16).
 template <int NOISE, bool LDS>
 __device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl, const XY* txy, const XY* tss,
                                                  const double* tP, const int self, const int Cn, const int idi,
@@ -460,7 +497,7 @@ __device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl,
                                                  const int* __restrict__ offById, const double* __restrict__ P,
                                                  const double* __restrict__ sx, const double* __restrict__ sy,
                                                  double& xi, double& yi, double& Pi) {
-  // nothing here feeds a decision: multiply-adds may fuse (the file is compiled with -ffp-contract=off)
+  // nothing here feeds a decision directly: multiply-adds may fuse (the file is compiled with -ffp-contract=off)
 #pragma clang fp contract(fast)
   auto load = [&](int e, XY& pos, XY& nrm, double& pr) {
     if constexpr (LDS) {
@@ -481,29 +518,24 @@ __device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl,
   const double sxi = ms.x, syi = ms.y;
   const int off = (NOISE == SC_NOISE_HOST) ? offById[idi] : 0;
   const uint64_t zbase = noise_base(w.noise_key, idi);
-  double tx = 0, ty = 0, qx = 0, qy = 0;
+  const double k_ss = w.dt * w.ss, k_pp = w.dt * (1 + w.pamp), k_0 = -2 * w.tp * w.dt;
+  double tx = 0, ty = 0;
 #pragma unroll
   for (int s = 0; s < kMaxNbr; ++s) {
     if (s < Cn) {
       XY op, os;
       double oP;
       load(js[s], op, os, oP);
-      double ex, ey;
-      collider_noise<NOISE>(w, zbase + (uint64_t)s * kGold, s, eta, off, ex, ey);
-      const double rx = xi - (op.x + ex), ry = yi - (op.y + ey);
+      double rx, ry;
+      pair_offset<NOISE>(w, zbase + (uint64_t)s * kGold, s, eta, off, xi - op.x, yi - op.y, rx, ry);
       const double rinv = rsqrt_nr(rx * rx + ry * ry);
-      const double nx = rx * rinv, ny = ry * rinv;
-      const double align = ((sxi - os.x) * nx + (syi - os.y) * ny) * w.ss;  // crate.py:347-349
-      const double fix = oP + Pi - 2 * w.tp;                                 // crate.py:351
-      const double kk = align + fix;
-      tx += kk * nx;
-      ty += kk * ny;
-      const double pp = Pi + oP;  // crate.py:301-304
-      qx += nx * pp;
-      qy += ny * pp;
+      const double dot = ((sxi - os.x) * rx + (syi - os.y) * ry) * rinv;  // (s_i - s_j) . n_ij
+      const double wr = fma(dot, k_ss, fma(Pi + oP, k_pp, k_0)) * rinv;
+      tx += wr * rx;
+      ty += wr * ry;
     }
   }
-  return PairSums{tx, ty, qx, qy};
+  return PairSums{tx, ty};
 }
 
 // Phases 3b-4 of pass B for one particle: the sum of the neighbors' start-of-tick velocities (from `tv`,
@@ -529,26 +561,22 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
       uy += ov.y;
     }
   }
-  const double tx = ps.tx, ty = ps.ty;
-  double qx = ps.qx, qy = ps.qy;
 
   // 4. per-particle epilogue
   double Ux = 0, Uy = 0, Cx = 0, Cy = 0, V = 0;
   {
 #pragma clang fp contract(fast)
-  vxi += w.dt * tx;  // crate.py:352
-  vyi += w.dt * ty;
+  vxi += ps.tx;  // crate.py:352 and the particle part of :306
+  vyi += ps.ty;
   vxi += w.dt * w.gx;  // crate.py:310
   vyi += w.dt * w.gy;
   if (ws >= 0) {
     const double* rec = wrec + 5 * (size_t)ws;
     Ux = rec[0]; Uy = rec[1]; Cx = rec[2]; Cy = rec[3]; V = rec[4];
-    qx += Ux * Pi;  // wall colliders carry pressure 0 and are not normalised (crate.py:286-293)
-    qy += Uy * Pi;
+    const double dpa = w.dt * w.pamp * Pi;  // wall colliders carry pressure 0 and are not normalised (crate.py:286-306)
+    vxi += dpa * Ux;
+    vyi += dpa * Uy;
   }
-  const double dpa = w.dt * w.pamp;
-  vxi += dpa * qx;  // crate.py:306
-  vyi += dpa * qy;
   const double dv = w.dt * w.visc;  // crate.py:319-323: sum_j (v0_j - v_i), v_i the current velocity
   vxi += dv * (ux - C * vxi);
   vyi += dv * (uy - C * vyi);
@@ -668,7 +696,13 @@ __global__ void __launch_bounds__(kTileW)
   }
   const bool in_lds = total <= kTileCapB;
   const bool ghost = w.slab && (cpacked & kGhostBit);
+#if defined(SC_ABL_B_NOPAIRS)
+  const int C = 0;
+#elif defined(SC_ABL_CAPC)
+  const int C = live ? min(Craw, SC_ABL_CAPC) : 0;
+#else
   const int C = live ? Craw : 0;
+#endif
   const int Cn = ghost ? 0 : C;  // ghosts serve as neighbors only
   const int ws = live ? ws_raw : -1;
 
@@ -709,7 +743,7 @@ __global__ void __launch_bounds__(kTileW)
   const bool active = live && !ghost;
   const int self = i - tl.a0;
   if (in_lds) {
-    PairSums ps{0, 0, 0, 0};
+    PairSums ps{0, 0};
     double xi = 0, yi = 0, Pi = 0;
     if (active) ps = pass_b_pairs<NOISE, true>(w, tl, txy, tss, tP, self, Cn, idi, js, x, y, eta, offById, P, sx, sy, xi, yi, Pi);
     __syncthreads();  // everybody is done with (x, y): the array now takes the velocities

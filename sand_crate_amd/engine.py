@@ -228,6 +228,11 @@ class Engine:
 
     # -- RCCL transport of the halo exchange (optional; see the header)
     @staticmethod
+    def comm_available(rccl_path: str | None = None) -> bool:
+        """True when librccl can be loaded here (sc_comm_available); never raises."""
+        return N.load().sc_comm_available(rccl_path.encode() if rccl_path else None) == 0
+
+    @staticmethod
     def comm_unique_id(rccl_path: str | None = None) -> bytes:
         buf = C.create_string_buffer(128)
         N.check(N.load().sc_comm_unique_id(rccl_path.encode() if rccl_path else None, C.cast(buf, N._P)))

@@ -191,6 +191,7 @@ class SlabCrate:
         self.right = self.rank + 1 if self.rank < self.world - 1 else None
         self.backend = backend if backend is not None else HipSlabBackend(capacity, halo_capacity, device, noise, noise_seed)
         self.backend.set_slab(self.lo, self.hi, HALO_COLUMNS, self.left is not None, self.right is not None)
+        self._own_mask = own
         self.backend.load(p[own], v[own], ids)
         self._host_staged = dist.is_initialized() and dist.get_backend(group) != "nccl"
         self._stage = {}
@@ -201,6 +202,24 @@ class SlabCrate:
             raise ValueError("transport must be 'rccl' or 'torch'")
         if want == "rccl" and self.world > 1 and not self._host_staged and hasattr(self.backend, "exchange_rccl"):
             self._try_rccl()
+
+    def reload(self, particles, velocities) -> None:
+        """Start over from a state with the SAME particle positions as the one this object was built with (same
+        cuts, same owners): bodies back to their YAML placement, tick 0, the rank's particles uploaded again.
+        The communicator and the halo buffers are kept -- bench.py repeats its measurement this way."""
+        p = np.ascontiguousarray(particles, dtype=np.float64).reshape(-1, 2)
+        v = np.ascontiguousarray(velocities, dtype=np.float64).reshape(-1, 2)
+        if len(p) != len(self._own_mask):
+            raise ValueError("reload needs the particle count the slabs were cut for")
+        self.synchronize()
+        self.rigid_bodies = build_rigid_bodies(self.world_config.rigid_bodies)
+        self._pad_cache = {}
+        self.tick = 0
+        own = self._own_mask
+        self.backend.load(p[own], v[own], np.flatnonzero(own).astype(np.int64))
+        for name in ("packed_ahead", "_promised", "_inputs", "_params_key"):
+            if hasattr(self.backend, name):
+                setattr(self.backend, name, False if name == "packed_ahead" else None)
 
     # ------------------------------------------------------------------ stepping
     @property
@@ -227,6 +246,10 @@ class SlabCrate:
             return bool(flag.item())
 
         path = be.bundled_rccl()
+        # every rank must be able to load librccl BEFORE anyone enters the collective communicator set-up: a rank
+        # that fails there would return at once and leave the others blocked inside ncclCommInitRank
+        if not all_ok(be.engine.comm_available(path)):
+            return
         uid = torch.zeros(128, dtype=torch.uint8, device=dev)
         ok = True
         if self.rank == 0:
@@ -318,6 +341,9 @@ class SlabCrate:
                 self._exchange()
                 be.unpack(self.left is not None, self.right is not None)
             nxt = None
+            for body in self.rigid_bodies:  # crate.py:311-314: this tick's gravity step on free bodies
+                if body.moves and not body.driven:
+                    body.center_velocity = body.center_velocity + self.dt * self.gravity
             if k + 1 < n_ticks:  # nobody can edit coefficients inside run(): the next tick's inputs are known
                 for body in self.rigid_bodies:
                     body.apply_velocity(self.dt)
