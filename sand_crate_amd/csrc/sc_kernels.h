@@ -434,12 +434,25 @@ __global__ void __launch_bounds__(kRankTile)
 // The bucket slot receives the sort key (x) and the particle's storage index, so that K4 ranks
 // over CONTIGUOUS keys instead of chasing perm -> x.
 // ------------------------------------------------------------------------------------------
+// XCD-aware block -> chunk mapping (same idea as sc_tiled.h: tile_of_block): workgroups are dealt round-robin over
+// the 8 XCDs, so giving every XCD one contiguous run of chunks keeps neighboring chunks -- whose gathers and
+// scattered stores fall into the same cache lines -- inside one L2.  Placement is a speed matter only.
+__device__ __forceinline__ int chunk_of_block() {
+#ifdef SC_NO_XCD_CHUNKS
+  return blockIdx.x;
+#else
+  const int nb = gridDim.x, b = blockIdx.x;
+  const int q = nb >> 3, r = nb & 7, xcd = b & 7;
+  return xcd * q + min(xcd, r) + (b >> 3);
+#endif
+}
+
 __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ counters, const int* __restrict__ cellS,
                                                     const double* __restrict__ xS, const int* __restrict__ idS,
                                                     Buckets bk, int* __restrict__ cellCount,
                                                     int* __restrict__ perm, double* __restrict__ keyX,
                                                     int* __restrict__ keyId, int cap) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int i = chunk_of_block() * blockDim.x + threadIdx.x;
   const int ic = min(i, cap - 1);  // loads that do not depend on the stored count go out first
   int c = cellS[ic];
   const double xi = xS[ic];
@@ -479,7 +492,7 @@ __global__ void __launch_bounds__(kReorderBlock)
   __shared__ double ckx[kRankChunk];
   __shared__ int cki[kRankChunk];
   __shared__ int pick;
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = chunk_of_block() * blockDim.x + threadIdx.x;
   const bool live = s < counters[C_NT];
   int i = 0, idi = 0, cpacked = 0, c = 0, wsi = 0, b = 0, e = 0;
   double xi = 0, yi = 0, vxi = 0, vyi = 0;

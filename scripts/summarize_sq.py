@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Turns the counter CSVs of scripts/collect_sq.sh into profiles/r02_sq_<N>.json: per kernel, the average of every
+counter per launch (summed over the chip, as rocprofv3 reports it)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+out_dir, n = sys.argv[1], int(sys.argv[2])
+names = {"k_wall_bin": "wall_bin", "k_scan_cells": "cell_scan", "k_scatter": "scatter", "k_reorder": "reorder",
+         "k_pass_a": "neighbors_density", "k_pass_b": "force_integrate", "k_rank_big": "rank_big"}
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(lambda: collections.Counter())
+for f in sorted(glob.glob(f"{out_dir}/p*/*/*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        name = next((v for key, v in names.items() if key in k), None)
+        if name is None:
+            continue
+        agg[name][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[name][r["Counter_Name"]] += 1
+res = {"particles": n,
+       "source": "rocprofv3 --kernel-trace --pmc <4 SQ counters per pass>, bench.py --steps 20 --warmup 5 --repeats 1; "
+                 "average per launch, summed over the chip; SQ_ACTIVE_* / SQ_WAVE_CYCLES / SQ_WAIT_* in quad-cycles",
+       "kernels": {k: {c: agg[k][c] / cnt[k][c] for c in sorted(agg[k])} for k in sorted(agg)}}
+path = f"profiles/r02_sq_{n}.json"
+json.dump(res, open(path, "w"), indent=1)
+for k, v in res["kernels"].items():
+    if "SQ_INSTS_VALU" not in v:
+        continue
+    g = v.get("GRBM_GUI_ACTIVE", 0) / 8
+    print(f"{k:20s} VALU insts/particle {v['SQ_INSTS_VALU']/n:6.2f}  VALU busy {4*v.get('SQ_ACTIVE_INST_VALU',0)/1024/max(g,1):5.2f}  "
+          f"LDS busy {4*v.get('SQ_ACTIVE_INST_LDS',0)/1024/max(g,1):5.2f}  waves/SIMD {4*v.get('SQ_WAVE_CYCLES',0)/1024/max(g,1):5.2f}  "
+          f"LDS idx active/CU {v.get('SQ_LDS_IDX_ACTIVE',0)/256/max(g,1):5.2f}  bank conflict/CU {v.get('SQ_LDS_BANK_CONFLICT',0)/256/max(g,1):5.2f}  cycles {g:9.0f}")
+print("wrote", path)
