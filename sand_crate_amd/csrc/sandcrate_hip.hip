@@ -1252,6 +1252,16 @@ int sc_owned_count(sc_ctx* c, int64_t* n) {
   return SC_OK;
 }
 
+#ifdef SC_STAMPS
+// diagnostic build: copies the stamp buffer (2 kernels x 65536 waves x 16 slots, int64) to the host
+int sc_debug_stamps(sc_ctx* c, long long* out) {
+  if (!c || !out) return fail(SC_ERR_ARG, "null argument");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(sc::g_stamps), sizeof(long long) * 2 * sc::kStampWaves * sc::kStampSlots));
+  return SC_OK;
+}
+#endif
+
 // ---- timing -----------------------------------------------------------------------------------
 
 static int harvest(sc_ctx* c) {

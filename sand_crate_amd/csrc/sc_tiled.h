@@ -30,10 +30,27 @@
 
 namespace sc {
 
+// Diagnostic build only (-DSC_STAMPS): per-wave clock stamps at phase boundaries, drained (s_waitcnt 0) so that a
+// stamp means "everything before is done".  The stamps go to a buffer no kernel reads (sc_debug_stamps reads it
+// on the host); the product build compiles none of this.
+#ifdef SC_STAMPS
+constexpr int kStampSlots = 16, kStampWaves = 1 << 16;
+__device__ long long g_stamps[2][kStampWaves][kStampSlots];
+#define SC_STAMP(kernel, slot)                                                                          \
+  do {                                                                                                   \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                         \
+    const long long now_ = __builtin_amdgcn_s_memtime();                                                 \
+    const int wv_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                                 \
+    if ((threadIdx.x & 63) == 0 && wv_ < kStampWaves) g_stamps[kernel][wv_][slot] = now_;                \
+  } while (0)
+#else
+#define SC_STAMP(kernel, slot) do { } while (0)
+#endif
+
 // Tile geometry (measured, profiles/README.md): 256 particles per workgroup beat 128 by 2-3 % (less halo per
 // particle: 3 x (256 + 12) entries for 256 particles) and 64 lose 3-6 %.
 #ifndef SC_SCAN_BATCH
-#define SC_SCAN_BATCH 2
+#define SC_SCAN_BATCH 4
 #endif
 #ifndef SC_TILE_W
 #define SC_TILE_W 256
@@ -138,6 +155,8 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       //   particle still sees its candidates in the reference's order, so the lists are the same.
       constexpr int kHalf = CAP / 2, kSerial = 32;
       const double dstop = w.d * (1.0 + 0x1p-20);
+      unsigned short* lp = &list[0][t];                  // next free entry of this thread's list (LDS tiles)
+      unsigned short* const lend = &list[kMaxNbr][t];
       auto scan = [&](bool want, int first, int count, int step, auto window) {
         if constexpr (LDS) {
           // kBatch candidates per iteration: their LDS reads are issued together (one latency per batch
@@ -146,27 +165,30 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
           // beyond d (1 + 2^-20) in x can neither be in the window nor within d); a hit is decided
           // exactly -- the reference's window expression AND the distance predicate.
           constexpr int kBatch = SC_SCAN_BATCH;
-          bool done = !want;
+          // The last candidate of a batch may lie one to kBatch - 1 slots past the range: the tile array has that
+          // much padding at both ends, what is read there is never a hit (v + k < count).  x is monotone along a
+          // scan, so the last candidate of the batch decides the stop.
+          bool done = !want || lp == lend;
           for (int v = 0; v < count && !done; v += kBatch) {
             XY q[kBatch];
 #pragma unroll
-            for (int k = 0; k < kBatch; ++k) q[k] = txy[first + (v + k < count ? v + k : v) * step];
+            for (int k = 0; k < kBatch; ++k) q[k] = txy[first + (v + k) * step];
             bool hit[kBatch];
-            bool stop = false;
 #pragma unroll
             for (int k = 0; k < kBatch; ++k) {
               const double dx = q[k].x - xi, dy = q[k].y - yi;
-              stop |= step > 0 ? dx > dstop : dx < -dstop;
               hit[k] = dx * dx + dy * dy <= w.t_nbr && window(q[k].x, xi) == 2 && v + k < count;
             }
+            const double dxl = q[kBatch - 1].x - xi;
+            const bool stop = step > 0 ? dxl > dstop : dxl < -dstop;
 #pragma unroll
             for (int k = 0; k < kBatch; ++k) {
-              if (hit[k] && C < kMaxNbr) {  // trim (:91-93)
-                list[C][t] = (unsigned short)(first + (v + k) * step);
-                ++C;
+              if (hit[k] && lp != lend) {  // trim (:91-93)
+                *lp = (unsigned short)(first + (v + k) * step);
+                lp += kTileW + 2;
               }
             }
-            done = stop || C == kMaxNbr;
+            done = stop || lp == lend;
           }
         } else {
           const int lane = t & 63, wave0 = t & ~63;
@@ -252,14 +274,18 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       };
       // same strip, after i: x_j <= x_i + d                                  (:106-109)
       scan(live, self + 1, e0 - (i + 1), 1, [&](double xj, double xq) { return xj > xq + w.d ? 0 : 2; });
+      SC_STAMP(0, 3);
       // next strip: x_i - d <= x_j <= x_i + d                                (:112-119)
       scan(live && C < kMaxNbr, tl.n0 + (b1 - tl.a1), e1 - b1, 1,
            [&](double xj, double xq) { return xj > xq + w.d ? 0 : (xj >= xq - w.d ? 2 : 1); });
+      SC_STAMP(0, 4);
       // reverse edges (:85-88): i is a forward candidate of j, same strip
       scan(live && C < kMaxNbr, self - 1, i - b0, -1, [&](double xj, double xq) { return !(xq <= xj + w.d) ? 0 : 2; });
+      SC_STAMP(0, 5);
       // reverse edges from the previous strip
       scan(live && C < kMaxNbr, tl.n0 + tl.n1 + (em - 1 - tl.a2), em - bm, -1,
            [&](double xj, double xq) { return !(xq <= xj + w.d) ? 0 : (xq >= xj - w.d ? 2 : 1); });
+      if constexpr (LDS) C = (int)(lp - &list[0][t]) / (kTileW + 2);
     } else if (live) {
       // a tile beyond 65535 particles (a block inside one gigantic bucket) cannot use u16 slots:
       // entries go straight to the table as -(index+1); correctness path only
@@ -305,6 +331,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
 #ifdef SC_ABL_A_NOENUM
   C = 0;
 #endif
+  SC_STAMP(0, 6);
   // 4. pair math of pass A: populate_colliders (crate.py:161-175), pressures (:261-275), normals (:337-342)
   if (DENS && live) {
     // nothing here feeds a decision: multiply-adds may fuse (the file is compiled with -ffp-contract=off)
@@ -359,12 +386,14 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
     sy[i] = ay;
   }
 
+  SC_STAMP(0, 7);
   // 5. lists out, slot-major: for a fixed slot consecutive threads write consecutive words
   if (ENUM && live) {
     if (slots_fit)
       for (int s = 0; s < C; ++s) nbr16[(size_t)s * cap + i] = list[s][t];
     cnt[i] = (unsigned char)C;
   }
+  SC_STAMP(0, 8);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -386,7 +415,9 @@ __global__ void __launch_bounds__(kTileW)
              int* __restrict__ nbr, unsigned short* __restrict__ nbr16, unsigned char* __restrict__ cnt, int cap,
              const double* __restrict__ eta, const int* __restrict__ offById, double* __restrict__ P, double* __restrict__ sx,
              double* __restrict__ sy, int* __restrict__ tileBounds) {
-  __shared__ XY txy[CAP];
+  constexpr int kPad = SC_SCAN_BATCH - 1;  // a batched scan may read this far past either end of the tile
+  __shared__ XY txy_padded[CAP + 2 * kPad];
+  XY* const txy = txy_padded + kPad;
   __shared__ unsigned short list[kMaxNbr][kTileW + 2];  // tile slots of the neighbors, [slot][thread]
   __shared__ int bounds[6];
   __shared__ int wkey[2 * (kTileW / 64)];
@@ -395,6 +426,7 @@ __global__ void __launch_bounds__(kTileW)
   const int tile_id = tile_of_block();
   const int i0 = tile_id * kTileW;
   const int i = i0 + t;
+  SC_STAMP(0, 0);
   // everything that does not depend on the live count is requested before the count is waited for
   const int ic = min(i, cap - 1);
   const int cpacked = cell[ic];
@@ -425,6 +457,7 @@ __global__ void __launch_bounds__(kTileW)
       bounds[5] = em;
     }
   }
+  SC_STAMP(0, 1);
   __syncthreads();
   Tile tl;
   tl.a0 = bounds[0];
@@ -457,6 +490,7 @@ __global__ void __launch_bounds__(kTileW)
     }
   }
   __syncthreads();
+  SC_STAMP(0, 2);
   if (ENUM && t < 6) tileBounds[6 * tile_id + t] = bounds[t];  // pass B stages the same three ranges
 
   if (in_lds)
@@ -655,6 +689,7 @@ __global__ void __launch_bounds__(kTileW)
   const int tile_id = tile_of_block();
   const int i0 = tile_id * kTileW;
   const int i = i0 + t;
+  SC_STAMP(1, 0);
   // 1. one round trip: the three ranges (published by pass A for this very block), the particle's
   // scalars and all twenty table entries -- none of these loads waits for another
   const int ic = min(i, cap - 1);
@@ -679,6 +714,7 @@ __global__ void __launch_bounds__(kTileW)
     progress[2] = n;           // ... and sizes heuristics by a recent live count
   }
   if (i0 >= n) return;
+  SC_STAMP(1, 1);
   const int m = min(kTileW, n - i0);
   const bool live = t < m;
 
@@ -737,6 +773,7 @@ __global__ void __launch_bounds__(kTileW)
   }
   __syncthreads();
 
+  SC_STAMP(1, 2);
   // 3-4. pair math and epilogue; ghosts and lanes without a particle skip it
   double xn = __builtin_huge_val(), yn = 0.0, vxn = 0.0, vyn = 0.0;  // a ghost's copy: +inf makes the next
   int idn = -1;                                                        // removal test (crate.py:152) drop it
@@ -746,6 +783,7 @@ __global__ void __launch_bounds__(kTileW)
     PairSums ps{0, 0};
     double xi = 0, yi = 0, Pi = 0;
     if (active) ps = pass_b_pairs<NOISE, true>(w, tl, txy, tss, tP, self, Cn, idi, js, x, y, eta, offById, P, sx, sy, xi, yi, Pi);
+    SC_STAMP(1, 3);
     __syncthreads();  // everybody is done with (x, y): the array now takes the velocities
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
@@ -753,6 +791,7 @@ __global__ void __launch_bounds__(kTileW)
       if (s < total) txy[s] = rv[k];
     }
     __syncthreads();
+    SC_STAMP(1, 4);
     if (active) {
       idn = idi;
       pass_b_finish<true>(w, tl, txy, C, Cn, ws, js, vx, vy, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn);
@@ -763,6 +802,7 @@ __global__ void __launch_bounds__(kTileW)
     const PairSums ps = pass_b_pairs<NOISE, false>(w, tl, txy, tss, tP, self, Cn, idi, js, x, y, eta, offById, P, sx, sy, xi, yi, Pi);
     pass_b_finish<false>(w, tl, txy, C, Cn, ws, js, vx, vy, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn);
   }
+  SC_STAMP(1, 5);
   if (FUSED) {
     int cnext = -1, wsn = -1;
     const double xp = xn, yp = yn;  // as integrated: what a halo message carries (the receiver runs its own K1)
@@ -778,6 +818,7 @@ __global__ void __launch_bounds__(kTileW)
       halo_pack_one(active, xp, yp, vxn, vyn, idn, wn.d, w.own_lo, w.own_hi, w.halo, w.has_left, w.has_right, haloL,
                     haloR, haloCap, counters);
   }
+  SC_STAMP(1, 6);
   if (live) {
     xo[i] = xn;
     yo[i] = yn;
@@ -785,6 +826,7 @@ __global__ void __launch_bounds__(kTileW)
     vyo[i] = vyn;
     ido[i] = idn;
   }
+  SC_STAMP(1, 7);
 }
 
 }  // namespace sc
