@@ -693,7 +693,7 @@ int sc_step_begin(sc_ctx* c) {
     hipLaunchKernelGGL(k_reorder, dim3((int)std::max<int64_t>(1, (launch_bound(c) + kReorderBlock - 1) / kReorderBlock)),
                        dim3(kReorderBlock), 0, c->stream, c->counters, c->perm, c->keyX, c->keyId,
                        c->cellS, Buckets{c->cellStart, c->blockOff}, c->wslotS, c->y[0], c->vx[0], c->vy[0], c->x[1], c->y[1], c->vx[1],
-                       c->vy[1], c->id[1], c->cellT, c->wslotT, c->sortedStamp, stamp, c->rankAcc);
+                       c->vy[1], c->id[1], c->cellT, c->wslotT, c->sortedStamp, stamp, c->rankAcc, w.ncols, c->tileBounds);
   }
   // SC_NOISE_HOST (and the stand-alone search) stop after the lists: the host's rand block can only be
   // indexed once every count is known.  Otherwise the search and pass A are one launch.

@@ -7,6 +7,9 @@
 
 namespace sc {
 
+#ifndef SC_TILE_W
+#define SC_TILE_W 256
+#endif
 constexpr int kBlock = 256;          // 4 wave64 per workgroup
 constexpr int kMaxNbr = SC_MAX_NEIGHBORS;
 constexpr int kMaxSeg = SC_MAX_SEGMENTS;

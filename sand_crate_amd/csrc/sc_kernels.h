@@ -488,12 +488,14 @@ __global__ void __launch_bounds__(kReorderBlock)
               const int* __restrict__ wslotS, const double* __restrict__ yS, const double* __restrict__ vxS,
               const double* __restrict__ vyS, double* __restrict__ xT, double* __restrict__ yT,
               double* __restrict__ vxT, double* __restrict__ vyT, int* __restrict__ idT, int* __restrict__ cellT,
-              int* __restrict__ wslotT, const int* __restrict__ sortedStamp, int stamp, int* __restrict__ rankAcc) {
+              int* __restrict__ wslotT, const int* __restrict__ sortedStamp, int stamp, int* __restrict__ rankAcc,
+              int ncols, int* __restrict__ tileBounds) {
   __shared__ double ckx[kRankChunk];
   __shared__ int cki[kRankChunk];
   __shared__ int pick;
   const int s = chunk_of_block() * blockDim.x + threadIdx.x;
-  const bool live = s < counters[C_NT];
+  const int nlive = counters[C_NT];
+  const bool live = s < nlive;
   int i = 0, idi = 0, cpacked = 0, c = 0, wsi = 0, b = 0, e = 0;
   double xi = 0, yi = 0, vxi = 0, vyi = 0;
   if (live) {
@@ -564,6 +566,21 @@ __global__ void __launch_bounds__(kReorderBlock)
   }
   if (!live) return;
   const int dst = b + rank;
+  // The candidates of a block of SC_TILE_W consecutive sorted particles lie in three index ranges (sc_tiled.h);
+  // the block's first and last particle know them from their cells.  Published here, one kernel ahead of the
+  // tiled passes, so that those can stage their tile without waiting for bucket lookups of their own.
+  if (dst % SC_TILE_W == 0) {
+    int* tb = tileBounds + 6 * (dst / SC_TILE_W);
+    tb[0] = bk(c - 1);
+    tb[2] = bk(c + ncols - 1);
+    tb[4] = bk(c - ncols - 1);
+  }
+  if (dst % SC_TILE_W == SC_TILE_W - 1 || dst == nlive - 1) {
+    int* tb = tileBounds + 6 * (dst / SC_TILE_W);
+    tb[1] = bk(c + 2);
+    tb[3] = bk(c + ncols + 2);
+    tb[5] = bk(c - ncols + 2);
+  }
   xT[dst] = xi;
   yT[dst] = yi;
   vxT[dst] = vxi;

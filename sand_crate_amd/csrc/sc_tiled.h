@@ -52,8 +52,7 @@ __device__ long long g_stamps[2][kStampWaves][kStampSlots];
 #ifndef SC_SCAN_BATCH
 #define SC_SCAN_BATCH 4
 #endif
-#ifndef SC_TILE_W
-#define SC_TILE_W 256
+#ifndef SC_CAP_A
 #define SC_CAP_A 1024
 #define SC_CAP_AW 1536
 #define SC_CAP_B 960
@@ -414,12 +413,11 @@ __global__ void __launch_bounds__(kTileW)
              const int* __restrict__ id, const int* __restrict__ cell, Buckets bk,
              int* __restrict__ nbr, unsigned short* __restrict__ nbr16, unsigned char* __restrict__ cnt, int cap,
              const double* __restrict__ eta, const int* __restrict__ offById, double* __restrict__ P, double* __restrict__ sx,
-             double* __restrict__ sy, int* __restrict__ tileBounds) {
+             double* __restrict__ sy, const int* __restrict__ tileBounds) {
   constexpr int kPad = SC_SCAN_BATCH - 1;  // a batched scan may read this far past either end of the tile
   __shared__ XY txy_padded[CAP + 2 * kPad];
   XY* const txy = txy_padded + kPad;
   __shared__ unsigned short list[kMaxNbr][kTileW + 2];  // tile slots of the neighbors, [slot][thread]
-  __shared__ int bounds[6];
   __shared__ int wkey[2 * (kTileW / 64)];
 
   const int t = threadIdx.x;
@@ -431,12 +429,22 @@ __global__ void __launch_bounds__(kTileW)
   const int ic = min(i, cap - 1);
   const int cpacked = cell[ic];
   const int idi = (DENS && NOISE != SC_NOISE_NONE) ? id[ic] : 0;
+  // the tile's three ranges: k_reorder published them, so staging need not wait for the bucket lookups below
+  const int* tb = tileBounds + 6 * tile_id;
+  const int tb0 = tb[0], tb1 = tb[1], tb2 = tb[2], tb3 = tb[3], tb4 = tb[4], tb5 = tb[5];
   const int n = counters[C_NT];
   if (i0 >= n) return;
   const int m = min(kTileW, n - i0);
   const bool live = t < m;
 
-  // 1. own candidate ranges (cell -> six bucket boundaries); first / last thread publish the tile
+  // 1. the particle's own candidate ranges (cell -> six bucket boundaries)
+  Tile tl;
+  tl.a0 = tb0;
+  tl.n0 = tb1 - tb0;
+  tl.a1 = tb2;
+  tl.n1 = tb3 - tb2;
+  tl.a2 = tb4;
+  tl.n2 = tb5 - tb4;
   int e0 = 0, b0 = 0, b1 = 0, e1 = 0, bm = 0, em = 0;
   if (live) {
     const int c = cpacked & kCellMask;
@@ -446,26 +454,7 @@ __global__ void __launch_bounds__(kTileW)
     e1 = bk(c + w.ncols + 2);
     bm = bk(c - w.ncols - 1);
     em = bk(c - w.ncols + 2);
-    if (t == 0) {
-      bounds[0] = b0;
-      bounds[2] = b1;
-      bounds[4] = bm;
-    }
-    if (t == m - 1) {
-      bounds[1] = e0;
-      bounds[3] = e1;
-      bounds[5] = em;
-    }
   }
-  SC_STAMP(0, 1);
-  __syncthreads();
-  Tile tl;
-  tl.a0 = bounds[0];
-  tl.n0 = bounds[1] - tl.a0;
-  tl.a1 = bounds[2];
-  tl.n1 = bounds[3] - tl.a1;
-  tl.a2 = bounds[4];
-  tl.n2 = bounds[5] - tl.a2;
   const int total = tl.n0 + tl.n1 + tl.n2;
   // a tile that fits but is much denser than usual (some dense cell plus its sparse surroundings) is better off
   // on the windowed path, which hands long fruitless walks to the whole wave (measured: profiles/README.md)
@@ -489,9 +478,9 @@ __global__ void __launch_bounds__(kTileW)
       if (s < total) txy[s] = r[k];
     }
   }
+  SC_STAMP(0, 1);
   __syncthreads();
   SC_STAMP(0, 2);
-  if (ENUM && t < 6) tileBounds[6 * tile_id + t] = bounds[t];  // pass B stages the same three ranges
 
   if (in_lds)
     pass_a_body<NOISE, ENUM, DENS, true, CAP>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr, nbr16, cnt,
