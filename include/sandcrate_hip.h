@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 1
+#define SC_ABI_VERSION 2
 #define SC_MAX_NEIGHBORS 20 /* collision_detector.py:6  MAX_ALLOWED_NEIGHBORS */
 #define SC_MAX_SEGMENTS 16  /* wall segments of all rigid bodies together (scenes use 6 and 8) */
 #define SC_MAX_BODIES 8
@@ -213,7 +213,23 @@ const char* sc_kernel_name(int index);
 int sc_set_slab(sc_ctx* ctx, int64_t col_lo, int64_t col_hi, int32_t halo, int32_t has_left, int32_t has_right);
 int sc_upload_state_ids(sc_ctx* ctx, const double* xy, const double* vxy, const int64_t* ids, int64_t n);
 int sc_halo_pack(sc_ctx* ctx, double* dev_left, double* dev_right, int64_t capacity_records);
-int sc_halo_unpack(sc_ctx* ctx, const double* dev_from_left, const double* dev_from_right, int64_t capacity_records);
+/* Message sizes.  A message need not carry the whole buffer: sc_halo_sizes gives, for the exchange of the coming
+ * tick, the number of records (after the header record) to send to / receive from each side -- the count the same
+ * direction had six ticks earlier plus 50 % and 1024 records, in steps of 256, at most capacity_records.  Sender
+ * and receiver of a message derive it from the same number (what was packed = what the received header said;
+ * sc_halo_unpack publishes both in host-mapped memory), so the two ends agree without talking; the lag exceeds
+ * the number of ticks the host may run ahead of the device, so nothing synchronises.  Whole buffers for the
+ * first ticks after an upload or sc_set_slab.  sc_halo_unpack is told how many records each message carried; a
+ * header that announces more sets the halo-overflow condition (SC_ERR_CAPACITY at the next synchronising call). */
+int sc_halo_sizes(sc_ctx* ctx, int64_t capacity_records, int64_t* send_left_records, int64_t* recv_left_records,
+                  int64_t* send_right_records, int64_t* recv_right_records);
+int sc_halo_unpack(sc_ctx* ctx, const double* dev_from_left, int64_t left_records, const double* dev_from_right,
+                   int64_t right_records);
+/* Slab re-balancing: stored live particles per grid column floor(x / diameter), columns clamped into
+ * [col0, col0 + n_columns).  Every particle is stored live on exactly one rank, so the ranks' histograms add up
+ * to the global one, from which all ranks derive the same new cuts (sc_set_slab; the next halo exchange moves
+ * the particles that changed owner).  Synchronises. */
+int sc_column_histogram(sc_ctx* ctx, int64_t col0, int32_t n_columns, int64_t* histogram);
 /* RCCL transport for the exchange step (optional: any transport that moves the buffers between the
  * calls above will do; sand_crate_amd.slab falls back to torch.distributed P2P ops).  librccl is dlopen()ed
  * on first use -- the copy already loaded in the process if any, else `rccl_path`, else the default search
@@ -224,14 +240,15 @@ int sc_halo_unpack(sc_ctx* ctx, const double* dev_from_left, const double* dev_f
  *   sc_comm_init       collective over the `world` contexts of the slab chain (ncclCommInitRank); rank = slab index
  *   sc_halo_exchange   on the context's stream, one group: send `send_left` to / receive `recv_left` from
  *                      rank `left_rank`, the same on the right; a negative rank means no neighbor on that side.
- *                      All four buffers are (capacity_records + 1) * 5 doubles of device memory.
+ *                      Each message is (records + 1) * 5 doubles from the start of its buffer (sc_halo_sizes).
  * A failing RCCL call returns SC_ERR_HIP with RCCL's message in sc_last_error(). */
 int sc_comm_available(const char* rccl_path);
 int sc_comm_unique_id(const char* rccl_path, void* id_128_bytes);
 int sc_comm_init(sc_ctx* ctx, const char* rccl_path, const void* id_128_bytes, int32_t rank, int32_t world);
 int sc_comm_destroy(sc_ctx* ctx);
-int sc_halo_exchange(sc_ctx* ctx, const double* send_left, double* recv_left, int32_t left_rank,
-                     const double* send_right, double* recv_right, int32_t right_rank, int64_t capacity_records);
+int sc_halo_exchange(sc_ctx* ctx, const double* send_left, int64_t send_left_records, double* recv_left,
+                     int64_t recv_left_records, int32_t left_rank, const double* send_right, int64_t send_right_records,
+                     double* recv_right, int64_t recv_right_records, int32_t right_rank);
 
 /* Synchronises.  Live particles stored in this context (dead ghost copies excluded); summed over
  * the ranks this is the global particle count. */

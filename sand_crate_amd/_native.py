@@ -87,12 +87,14 @@ SIGNATURES = {
     "sc_set_slab": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "sc_upload_state_ids": (C.c_int, [_P, _D, _D, _I64, C.c_int64]),
     "sc_halo_pack": (C.c_int, [_P, _P, _P, C.c_int64]),
-    "sc_halo_unpack": (C.c_int, [_P, _P, _P, C.c_int64]),
+    "sc_halo_sizes": (C.c_int, [_P, C.c_int64, _I64, _I64, _I64, _I64]),
+    "sc_halo_unpack": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64]),
+    "sc_column_histogram": (C.c_int, [_P, C.c_int64, C.c_int32, _I64]),
     "sc_comm_available": (C.c_int, [C.c_char_p]),
     "sc_comm_unique_id": (C.c_int, [C.c_char_p, _P]),
     "sc_comm_init": (C.c_int, [_P, C.c_char_p, _P, C.c_int32, C.c_int32]),
     "sc_comm_destroy": (C.c_int, [_P]),
-    "sc_halo_exchange": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.c_int32, C.c_int64]),
+    "sc_halo_exchange": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P, C.c_int64, _P, C.c_int64, C.c_int32]),
     "sc_owned_count": (C.c_int, [_P, _I64]),
 }
 

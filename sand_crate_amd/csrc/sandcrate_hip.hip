@@ -87,9 +87,13 @@ struct sc_ctx {
   int comm_rank = -1, comm_world = 0;
   double *haloL = nullptr, *haloR = nullptr;  // send buffers of the last sc_halo_pack (caller-owned device memory)
   int haloCap = 0;
+  int64_t halo_ring_from = 0;  // first tick whose halo counts in the progress block belong to the current state
+  int* colHist = nullptr;      // sc_column_histogram
+  int64_t colHistAlloc = 0;
   int* rankAcc = nullptr;  // per bucket slot: rank inside a big bucket (k_rank_big adds, k_reorder takes and clears)
   // host-mapped progress block written by the GPU, read by the host without synchronisation:
-  // [0] big buckets seen by the last finished scan, [1] ticks finished, [2] live particles of that tick
+  // [0] big buckets seen by the last finished scan, [1] ticks finished, [2] live particles of that tick,
+  // [4 + 4 (tick % kHaloRing) ..]: halo record counts of that tick (sent left / right, received left / right)
   int* bigHintHost = nullptr;
   int* bigHintDev = nullptr;
   bool force_rank_big = false;
@@ -369,6 +373,7 @@ int put_particles(sc_ctx* c, const double* xy, const double* vxy, int64_t n, boo
   if (reset) {
     c->next_id = 0;
     c->normals_valid = 0;
+    c->halo_ring_from = c->tick;  // counts published before this belong to another state
   }
   if (c->next_id + n > std::numeric_limits<int>::max()) return fail(SC_ERR_CAPACITY, "particle ids exhausted");
   if (n > 0) {
@@ -490,9 +495,9 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
   if (e == hipSuccess) e = dalloc(&c->bigList, (size_t)kMaxBig);
   if (e == hipSuccess) e = dalloc(&c->rankAcc, n);
   if (e == hipSuccess) e = hipMemsetAsync(c->rankAcc, 0, n * sizeof(int), c->stream);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&c->bigHintHost, 4 * sizeof(int), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->bigHintHost, kProgressInts * sizeof(int), hipHostMallocMapped);
   if (e == hipSuccess) {
-    c->bigHintHost[0] = c->bigHintHost[1] = c->bigHintHost[2] = c->bigHintHost[3] = 0;
+    for (int k = 0; k < kProgressInts; ++k) c->bigHintHost[k] = 0;
     e = hipHostGetDevicePointer((void**)&c->bigHintDev, c->bigHintHost, 0);
   }
   if (e == hipSuccess) e = dalloc(&c->wrec[0], 5 * n);
@@ -528,7 +533,7 @@ int sc_destroy(sc_ctx* c) {
   }
   void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->rankAcc, c->wrec[0], c->wrec[1],
                   c->nbr, c->nbr16, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
-                  c->stage_xy, c->stage_vxy, c->stage_ids, c->owned_out};
+                  c->stage_xy, c->stage_vxy, c->stage_ids, c->owned_out, c->colHist};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& v : {c->ev_used, c->ev_free})
@@ -1115,7 +1120,68 @@ int sc_set_slab(sc_ctx* c, int64_t col_lo, int64_t col_hi, int32_t halo, int32_t
   c->halo = halo;
   c->has_left = has_left ? 1 : 0;
   c->has_right = has_right ? 1 : 0;
+  c->halo_ring_from = c->tick;  // new cuts: the halo counts of earlier ticks say nothing about the coming ones
   if (!c->owned_out) HIPCHK(dalloc(&c->owned_out, 1));
+  return SC_OK;
+}
+
+// Records a halo message of tick `tick` carries, from the count the same direction had `kHaloLag` ticks earlier
+// (+50 % and 1024 records of headroom, in steps of 256).  Sender and receiver evaluate this on the same number:
+// the sender published what it packed, the receiver what the header it received said.
+static int64_t halo_message_records(int64_t count, int64_t cap) {
+  const int64_t want = count + count / 2 + 1024;
+  return std::min<int64_t>(cap, (want + 255) / 256 * 256);
+}
+
+int sc_halo_sizes(sc_ctx* c, int64_t cap_records, int64_t* send_left, int64_t* recv_left, int64_t* send_right,
+                  int64_t* recv_right) {
+  if (!c || !send_left || !recv_left || !send_right || !recv_right || cap_records < 1) return fail(SC_ERR_ARG, "bad arguments");
+  if (!c->slab) return fail(SC_ERR_STATE, "sc_set_slab first");
+  constexpr int64_t kHaloLag = 6;  // more than the ticks the host may run ahead of the device (sc_step_begin)
+  static_assert(kHaloLag < kHaloRing, "the ring must still hold the tick the sizes come from");
+  *send_left = *recv_left = *send_right = *recv_right = cap_records;
+  const int64_t src = c->tick - kHaloLag;
+  if (src < c->halo_ring_from) return SC_OK;  // no history yet: whole buffers
+  // tick `src` has finished on the device (at most a few ticks are ever queued), so its counts are published
+  int spins = 0;
+  while ((int64_t) * (volatile int*)(c->bigHintHost + 1) <= src) {
+    if (++spins > 64) {
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) return fail(SC_ERR_HIP, "stream error while waiting for halo counts: %s", hipGetErrorString(q));
+      spins = 0;
+    }
+    sched_yield();
+  }
+  if ((int64_t) * (volatile int*)(c->bigHintHost + 1) <= src) return SC_OK;  // counter behind (fresh upload): whole buffers
+  const volatile int* ring = c->bigHintHost + 4 + 4 * (src % kHaloRing);
+  *send_left = halo_message_records(ring[0], cap_records);
+  *send_right = halo_message_records(ring[1], cap_records);
+  *recv_left = halo_message_records(ring[2], cap_records);
+  *recv_right = halo_message_records(ring[3], cap_records);
+  return SC_OK;
+}
+
+int sc_column_histogram(sc_ctx* c, int64_t col0, int32_t ncols, int64_t* hist) {
+  if (!c || !hist || ncols < 1) return fail(SC_ERR_ARG, "bad arguments");
+  if (c->in_step) return fail(SC_ERR_STATE, "sc_column_histogram inside a tick");
+  if (!c->have_params && !c->custom_grid) return fail(SC_ERR_STATE, "sc_set_params has not been called");
+  HIPCHK(hipSetDevice(c->device));
+  if (ncols > c->colHistAlloc) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->colHist) (void)hipFree(c->colHist);
+    c->colHist = nullptr;
+    HIPCHK(dalloc(&c->colHist, (size_t)ncols + 256));
+    c->colHistAlloc = ncols + 256;
+  }
+  HIPCHK(hipMemsetAsync(c->colHist, 0, ncols * sizeof(int), c->stream));
+  const double d = c->custom_grid ? c->custom_d : c->params.particle_radius * 2;
+  hipLaunchKernelGGL(k_column_histogram, dim3(grid_for(launch_bound(c))), dim3(kBlock), 0, c->stream, c->counters, c->x[0], d,
+                     (long long)col0, (int)ncols, c->colHist);
+  std::vector<int> h(ncols);
+  HIPCHK(hipMemcpyAsync(h.data(), c->colHist, ncols * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < ncols; ++k) hist[k] = h[k];
   return SC_OK;
 }
 
@@ -1142,22 +1208,26 @@ int sc_halo_pack(sc_ctx* c, double* dev_left, double* dev_right, int64_t cap_rec
   return SC_OK;
 }
 
-int sc_halo_unpack(sc_ctx* c, const double* from_left, const double* from_right, int64_t cap_records) {
-  if (!c || (!from_left && !from_right) || cap_records < 1) return fail(SC_ERR_ARG, "bad halo buffers");
+int sc_halo_unpack(sc_ctx* c, const double* from_left, int64_t left_records, const double* from_right,
+                   int64_t right_records) {
+  if (!c || (!from_left && !from_right) || (from_left && left_records < 1) || (from_right && right_records < 1))
+    return fail(SC_ERR_ARG, "bad halo buffers");
   if (!c->slab) return fail(SC_ERR_STATE, "sc_set_slab first");
   if (c->in_step) return fail(SC_ERR_STATE, "halo exchange happens between ticks");
   Bracket br(c, K_HALO_UNPACK);
-  const dim3 grid(grid_for(2 * cap_records)), block(kBlock);
+  const int capL = from_left ? (int)left_records : 0, capR = from_right ? (int)right_records : 0;
+  const dim3 grid(grid_for(capL + capR)), block(kBlock);
+  int* ring = c->bigHintDev + 4 + 4 * (int)(c->tick % kHaloRing);
   if (c->prebinned) {  // the stored particles went through K1 of the coming tick in pass B: same for the arrivals
-    hipLaunchKernelGGL(k_halo_unpack<true>, grid, block, 0, c->stream, from_left, from_right, (int)cap_records,
+    hipLaunchKernelGGL(k_halo_unpack<true>, grid, block, 0, c->stream, from_left, from_right, capL, capR,
                        c->counters, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], (int)c->cap, c->haloL, c->haloR,
-                       c->promised, c->cellS, c->wslotS, c->cellCount, c->wrec[c->tick & 1]);
+                       c->promised, c->cellS, c->wslotS, c->cellCount, c->wrec[c->tick & 1], ring);
   } else {
     WallInputs none;
     std::memset(&none, 0, sizeof none);
-    hipLaunchKernelGGL(k_halo_unpack<false>, grid, block, 0, c->stream, from_left, from_right, (int)cap_records,
+    hipLaunchKernelGGL(k_halo_unpack<false>, grid, block, 0, c->stream, from_left, from_right, capL, capR,
                        c->counters, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], (int)c->cap, c->haloL, c->haloR, none,
-                       c->cellS, c->wslotS, c->cellCount, c->wrec[c->tick & 1]);
+                       c->cellS, c->wslotS, c->cellCount, c->wrec[c->tick & 1], ring);
   }
   HIPCHK(hipGetLastError());
   return SC_OK;
@@ -1207,28 +1277,29 @@ int sc_comm_destroy(sc_ctx* c) {
   return SC_OK;
 }
 
-int sc_halo_exchange(sc_ctx* c, const double* send_left, double* recv_left, int32_t left_rank, const double* send_right,
-                     double* recv_right, int32_t right_rank, int64_t cap_records) {
-  if (!c || cap_records < 1) return fail(SC_ERR_ARG, "bad halo buffers");
+int sc_halo_exchange(sc_ctx* c, const double* send_left, int64_t send_left_records, double* recv_left,
+                     int64_t recv_left_records, int32_t left_rank, const double* send_right, int64_t send_right_records,
+                     double* recv_right, int64_t recv_right_records, int32_t right_rank) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
   if (!c->comm) return fail(SC_ERR_STATE, "sc_comm_init first");
   if (c->in_step) return fail(SC_ERR_STATE, "halo exchange happens between ticks");
-  if ((left_rank >= 0 && (!send_left || !recv_left || left_rank >= c->comm_world)) ||
-      (right_rank >= 0 && (!send_right || !recv_right || right_rank >= c->comm_world)))
-    return fail(SC_ERR_ARG, "neighbor ranks %d / %d need their buffers and must be below %d", left_rank, right_rank,
-                c->comm_world);
-  const size_t count = (size_t)(cap_records + 1) * kHaloFields;
+  if ((left_rank >= 0 && (!send_left || !recv_left || left_rank >= c->comm_world || send_left_records < 1 || recv_left_records < 1)) ||
+      (right_rank >= 0 && (!send_right || !recv_right || right_rank >= c->comm_world || send_right_records < 1 || recv_right_records < 1)))
+    return fail(SC_ERR_ARG, "neighbor ranks %d / %d need their buffers and record counts and must be below %d", left_rank,
+                right_rank, c->comm_world);
+  auto doubles = [](int64_t records) { return (size_t)(records + 1) * kHaloFields; };  // + the header record
   const RcclApi& r = rccl_api();
   HIPCHK(hipSetDevice(c->device));
   RCCLCHK(r.GroupStart());
   int rc = 0;
   // posting order is the same on every rank (left pair, then right pair): rank k's right pair meets rank k+1's left pair
   if (left_rank >= 0) {
-    if (!rc) rc = r.Send(send_left, count, kRcclDouble, left_rank, c->comm, c->stream);
-    if (!rc) rc = r.Recv(recv_left, count, kRcclDouble, left_rank, c->comm, c->stream);
+    if (!rc) rc = r.Send(send_left, doubles(send_left_records), kRcclDouble, left_rank, c->comm, c->stream);
+    if (!rc) rc = r.Recv(recv_left, doubles(recv_left_records), kRcclDouble, left_rank, c->comm, c->stream);
   }
   if (right_rank >= 0) {
-    if (!rc) rc = r.Send(send_right, count, kRcclDouble, right_rank, c->comm, c->stream);
-    if (!rc) rc = r.Recv(recv_right, count, kRcclDouble, right_rank, c->comm, c->stream);
+    if (!rc) rc = r.Send(send_right, doubles(send_right_records), kRcclDouble, right_rank, c->comm, c->stream);
+    if (!rc) rc = r.Recv(recv_right, doubles(recv_right_records), kRcclDouble, right_rank, c->comm, c->stream);
   }
   const int rc_end = r.GroupEnd();
   if (rc) return fail(SC_ERR_HIP, "RCCL: send/recv failed: %s", rccl_error(rc));

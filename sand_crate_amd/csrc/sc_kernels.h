@@ -738,15 +738,22 @@ __global__ void __launch_bounds__(kBlock)
 // (ticket) adds the two record counts to it.  FUSED (pass B of the previous tick ran K1 for the stored
 // particles): the stored count is the sorted count of that tick, nobody changes it, and the appended
 // particles get their K1 here.
+// `capL` / `capR`: records the transport actually moved from the left / right (the agreed message sizes of
+// sc_halo_sizes).  A header that announces more means records were cut off: F_HALO_OVERFLOW.  `ring`: the four
+// counts of this tick (sent left, sent right, received from the left, from the right) are published in
+// host-mapped memory, slot tick % kHaloRing, for the message sizes of a later tick.
+constexpr int kHaloRing = 8;
+constexpr int kProgressInts = 4 + 4 * kHaloRing;  // [big buckets, ticks finished, live count, -] + the ring
+
 template <bool FUSED>
 __global__ void __launch_bounds__(kBlock)
-    k_halo_unpack(const double* __restrict__ bufL, const double* __restrict__ bufR, int cap, int* __restrict__ counters,
-                  double* __restrict__ x, double* __restrict__ y, double* __restrict__ vx, double* __restrict__ vy,
-                  int* __restrict__ id, int capS, double* __restrict__ sendL, double* __restrict__ sendR, WallInputs wn,
-                  int* __restrict__ cellS, int* __restrict__ wslotS, int* __restrict__ cellCount,
-                  double* __restrict__ wrec_next) {
-  const int nl = bufL ? min(*reinterpret_cast<const int*>(bufL), cap) : 0;
-  const int nr = bufR ? min(*reinterpret_cast<const int*>(bufR), cap) : 0;
+    k_halo_unpack(const double* __restrict__ bufL, const double* __restrict__ bufR, int capL, int capR,
+                  int* __restrict__ counters, double* __restrict__ x, double* __restrict__ y, double* __restrict__ vx,
+                  double* __restrict__ vy, int* __restrict__ id, int capS, double* __restrict__ sendL,
+                  double* __restrict__ sendR, WallInputs wn, int* __restrict__ cellS, int* __restrict__ wslotS,
+                  int* __restrict__ cellCount, double* __restrict__ wrec_next, volatile int* __restrict__ ring) {
+  const int hl = bufL ? *reinterpret_cast<const int*>(bufL) : 0, hr = bufR ? *reinterpret_cast<const int*>(bufR) : 0;
+  const int nl = min(hl, capL), nr = min(hr, capR);
   const int base = FUSED ? counters[C_NT] : __hip_atomic_load(&counters[C_NS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   int cnext = -1;
@@ -769,25 +776,43 @@ __global__ void __launch_bounds__(kBlock)
       id[base + k] = (int)r[4];
     }
   }
+  auto finish = [&]() {  // one thread, after every workgroup has read what it needs
+    counters[C_NS] = min(base + nl + nr, capS);
+    if (hl > capL || hr > capR) atomicOr(&counters[C_FLAGS], F_HALO_OVERFLOW);
+    ring[0] = sendL ? *reinterpret_cast<const int*>(sendL) : 0;
+    ring[1] = sendR ? *reinterpret_cast<const int*>(sendR) : 0;
+    ring[2] = hl;
+    ring[3] = hr;
+    if (sendL) *reinterpret_cast<int*>(sendL) = 0;
+    if (sendR) *reinterpret_cast<int*>(sendR) = 0;
+  };
   if (FUSED) {
     count_cells(cnext, cellCount);  // every lane of the wave takes part
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      counters[C_NS] = min(base + nl + nr, capS);
-      if (sendL) *reinterpret_cast<int*>(sendL) = 0;
-      if (sendR) *reinterpret_cast<int*>(sendR) = 0;
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) finish();
     return;
   }
   __syncthreads();  // every thread of this workgroup has read `base`
   if (threadIdx.x == 0) {
     __threadfence();
     if (atomicAdd(&counters[C_TICKET], 1) == (int)gridDim.x - 1) {
-      counters[C_NS] = min(base + nl + nr, capS);
+      finish();
       counters[C_TICKET] = 0;
-      if (sendL) *reinterpret_cast<int*>(sendL) = 0;
-      if (sendR) *reinterpret_cast<int*>(sendR) = 0;
     }
   }
+}
+
+// Stored live particles per grid column, clamped into [col0, col0 + ncols): across the ranks every particle is
+// stored live exactly once, so the sum of the ranks' histograms is the global one (slab re-balancing).
+__global__ void __launch_bounds__(kBlock)
+    k_column_histogram(const int* __restrict__ counters, const double* __restrict__ x, double d, long long col0, int ncols,
+                       int* __restrict__ hist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= counters[C_NS]) return;
+  const double px = x[i];
+  if (!(fabs(px) < 1e300)) return;  // a dead ghost copy: its owner counts the particle
+  const long long col = (long long)floor(px / d);
+  const long long k = col - col0;
+  atomicAdd(&hist[k < 0 ? 0 : (k >= ncols ? ncols - 1 : (int)k)], 1);
 }
 
 // live particles in the storage arrays: everything but the dead ghost copies (x = +inf) a slab tick

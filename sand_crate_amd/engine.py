@@ -222,9 +222,21 @@ class Engine:
     def halo_pack(self, dev_left: int, dev_right: int, capacity_records: int) -> None:
         N.check(self._lib.sc_halo_pack(self._ctx, N._P(dev_left), N._P(dev_right), int(capacity_records)))
 
-    def halo_unpack(self, dev_from_left: int | None, dev_from_right: int | None, capacity_records: int) -> None:
-        N.check(self._lib.sc_halo_unpack(self._ctx, N._P(dev_from_left) if dev_from_left else None,
-                                         N._P(dev_from_right) if dev_from_right else None, int(capacity_records)))
+    def halo_sizes(self, capacity_records: int) -> tuple[int, int, int, int]:
+        """-> records to (send left, receive from the left, send right, receive from the right) in the coming exchange."""
+        a, b, c, d = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        N.check(self._lib.sc_halo_sizes(self._ctx, int(capacity_records), C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value
+
+    def halo_unpack(self, dev_from_left: int | None, left_records: int, dev_from_right: int | None,
+                    right_records: int) -> None:
+        N.check(self._lib.sc_halo_unpack(self._ctx, N._P(dev_from_left) if dev_from_left else None, int(left_records),
+                                         N._P(dev_from_right) if dev_from_right else None, int(right_records)))
+
+    def column_histogram(self, col0: int, n_columns: int) -> np.ndarray:
+        hist = np.zeros(int(n_columns), dtype=np.int64)
+        N.check(self._lib.sc_column_histogram(self._ctx, int(col0), int(n_columns), N.i64ptr(hist)))
+        return hist
 
     # -- RCCL transport of the halo exchange (optional; see the header)
     @staticmethod
@@ -249,11 +261,13 @@ class Engine:
         N.check(self._lib.sc_comm_destroy(self._ctx))
 
     def halo_exchange(self, send_left: int | None, recv_left: int | None, left_rank: int, send_right: int | None,
-                      recv_right: int | None, right_rank: int, capacity_records: int) -> None:
-        """Device pointers as ints; a negative rank = no neighbor on that side.  Enqueued on the context's stream."""
+                      recv_right: int | None, right_rank: int, sizes: tuple[int, int, int, int]) -> None:
+        """Device pointers as ints; a negative rank = no neighbor on that side; `sizes` as halo_sizes() gives them.
+        Enqueued on the context's stream."""
         ptr = lambda a: N._P(a) if a else None  # noqa: E731
-        N.check(self._lib.sc_halo_exchange(self._ctx, ptr(send_left), ptr(recv_left), int(left_rank), ptr(send_right),
-                                           ptr(recv_right), int(right_rank), int(capacity_records)))
+        sl, rl, sr, rr = (int(k) for k in sizes)
+        N.check(self._lib.sc_halo_exchange(self._ctx, ptr(send_left), sl, ptr(recv_left), rl, int(left_rank),
+                                           ptr(send_right), sr, ptr(recv_right), rr, int(right_rank)))
 
     def owned_count(self) -> int:
         n = C.c_int64(0)

@@ -17,6 +17,13 @@ Per tick
     know how many particles cross.  A particle that has left its slab is in the message too and is
     owned by the receiver from then on (migration rides the halo message).  There is no other
     collective on the data path.
+Message sizes
+    a message carries the records its direction had six ticks earlier plus headroom, not the whole buffer
+    (Engine.halo_sizes: sender and receiver derive the size from the same published count, nothing synchronises).
+Re-balancing
+    with `rebalance_every=K` the ranks add their column histograms every K ticks (one small all-reduce), derive
+    the same new cuts and let the next halo message move the particles that changed owner; a cut moves by at
+    most a quarter of the narrower slab next to it per re-balance.
 Same results as one GPU
     ids are global, tie-breaks use ids, and the collider noise is the counter-based hash of
     (seed, tick, id, slot), so an owned particle sees the same neighbor list, in the same order,
@@ -35,6 +42,10 @@ from .rigid_body import build_rigid_bodies
 
 HALO_COLUMNS = 3
 HALO_FIELDS = 5
+
+
+def torch_empty_like_cpu(t):
+    return t.new_empty(t.shape, device="cpu")
 
 
 def column_of(x: np.ndarray, diameter: float) -> np.ndarray:
@@ -65,6 +76,44 @@ def partition_columns(columns: np.ndarray, n_slabs: int, halo: int = HALO_COLUMN
         prev = c
     bounds = [-big] + cuts + [big]
     return [(bounds[k], bounds[k + 1]) for k in range(n_slabs)]
+
+
+def rebalanced_cuts(hist: np.ndarray, col0: int, slabs: list[tuple[int, int]], budget: int,
+                    halo: int = HALO_COLUMNS) -> list[tuple[int, int]]:
+    """New cuts from the global column histogram (`hist[k]` = particles in column col0 + k): every cut moves
+    towards the equal-count position, but by no more columns than hold `budget` particles (they all travel in
+    one halo message) and never past a quarter of the narrower slab next to it; slabs keep their minimum width.
+    A pure function of its arguments, so every rank arrives at the same cuts."""
+    n = len(slabs)
+    if n == 1:
+        return list(slabs)
+    cum = np.concatenate(([0], np.cumsum(hist)))
+    total = int(cum[-1])
+    first, last = col0, col0 + len(hist)  # the columns the histogram covers stand in for the open outer edges
+    edges = [first] + [lo for lo, _ in slabs[1:]] + [last]
+    min_width = 2 * halo + 2
+    cuts = []
+    for k in range(1, n):
+        old = edges[k]
+        target = col0 + int(np.searchsorted(cum, total * k / n, side="left"))
+        reach = max(1, min(old - edges[k - 1], edges[k + 1] - old) // 4)
+        new = min(max(target, old - reach), old + reach)
+        step = 1 if new > old else -1
+        c, moved = old, 0
+        while c != new:  # column by column until the message budget is used up
+            col = c if step > 0 else c - 1
+            moved += int(hist[min(max(col - col0, 0), len(hist) - 1)])
+            if moved > budget:
+                break
+            c += step
+        cuts.append(c)
+    for k in range(len(cuts)):  # minimum widths, left to right
+        lo = (cuts[k - 1] if k else first) + min_width
+        hi = last - (len(cuts) - k) * min_width
+        cuts[k] = min(max(cuts[k], lo), hi)
+    big = 2 ** 40
+    bounds = [-big] + cuts + [big]
+    return [(bounds[k], bounds[k + 1]) for k in range(n)]
 
 
 class HipSlabBackend:
@@ -113,9 +162,19 @@ class HipSlabBackend:
     def pack(self) -> None:
         self.engine.halo_pack(self.send_left.data_ptr(), self.send_right.data_ptr(), self.halo_capacity)
 
-    def unpack(self, from_left: bool, from_right: bool) -> None:
-        self.engine.halo_unpack(self.recv_left.data_ptr() if from_left else None,
-                                self.recv_right.data_ptr() if from_right else None, self.halo_capacity)
+    def message_sizes(self, whole: bool = False) -> tuple[int, int, int, int]:
+        """Records to (send left, receive from the left, send right, receive from the right) in the coming exchange."""
+        if whole:
+            return (self.halo_capacity,) * 4
+        return self.engine.halo_sizes(self.halo_capacity)
+
+    def unpack(self, from_left: bool, from_right: bool, sizes=None) -> None:
+        sizes = sizes or (self.halo_capacity,) * 4
+        self.engine.halo_unpack(self.recv_left.data_ptr() if from_left else None, sizes[1],
+                                self.recv_right.data_ptr() if from_right else None, sizes[3])
+
+    def column_histogram(self, col0: int, n_columns: int) -> np.ndarray:
+        return self.engine.column_histogram(col0, n_columns)
 
     def bundled_rccl(self) -> str | None:
         """torch's own librccl, the fallback path for dlopen when no copy is loaded yet."""
@@ -123,11 +182,11 @@ class HipSlabBackend:
         cand = os.path.join(os.path.dirname(self.torch.__file__), "lib", "librccl.so")
         return cand if os.path.exists(cand) else None
 
-    def exchange_rccl(self, left: int | None, right: int | None) -> None:
+    def exchange_rccl(self, left: int | None, right: int | None, sizes=None) -> None:
         """One RCCL group on the engine's stream: send/recv with both neighbors (sc_halo_exchange)."""
         self.engine.halo_exchange(self.send_left.data_ptr(), self.recv_left.data_ptr(), -1 if left is None else left,
                                   self.send_right.data_ptr(), self.recv_right.data_ptr(),
-                                  -1 if right is None else right, self.halo_capacity)
+                                  -1 if right is None else right, sizes or (self.halo_capacity,) * 4)
 
     def step(self, next_inputs=None) -> None:
         """The tick, one library call.  With the next tick's inputs promised, the force kernel also runs that
@@ -153,14 +212,23 @@ class SlabCrate:
 
     def __init__(self, world_config, particles, velocities, *, device: int = 0, noise: str = "counter",
                  noise_seed: int = 0, group=None, backend=None, halo_capacity: int | None = None,
-                 capacity: int | None = None, transport: str | None = None):
+                 capacity: int | None = None, transport: str | None = None, rebalance_every: int = 0,
+                 cuts: list[int] | None = None, rank: int | None = None, world: int | None = None):
+        """`rank` / `world` given: a member of an in-process `SlabChain` (the chain moves the messages and adds the
+        histograms); otherwise they come from torch.distributed."""
         import torch.distributed as dist
         if noise == "host":
             raise ValueError("slabs need noise='counter' or 'none' (the host MT19937 stream is one global sequence)")
         self.dist = dist
         self.group = group
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._chained = rank is not None
+        if self._chained:
+            self.rank, self.world = int(rank), int(world)
+        else:
+            self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+            self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rebalance_every = int(rebalance_every)
+        self.rebalances = 0
         self.world_config = world_config
         self.rigid_bodies = build_rigid_bodies(world_config.rigid_bodies)
         if world_config.particle_sources:
@@ -176,6 +244,11 @@ class SlabCrate:
         d = self.particle_radius * 2
         cols = column_of(p[:, 0], d)
         self.slabs = partition_columns(cols, self.world)
+        if cuts is not None:  # the caller's cut columns instead of the equal-count ones
+            if len(cuts) != self.world - 1 or any(b - a < 2 * HALO_COLUMNS + 2 for a, b in zip(cuts[:-1], cuts[1:])):
+                raise ValueError("cuts: world - 1 increasing columns, at least 2 * halo + 2 apart")
+            bounds = [-2 ** 40] + [int(c) for c in cuts] + [2 ** 40]
+            self.slabs = [(bounds[k], bounds[k + 1]) for k in range(self.world)]
         self.lo, self.hi = self.slabs[self.rank]
         own = (cols >= self.lo) & (cols < self.hi)
         ids = np.flatnonzero(own).astype(np.int64)
@@ -193,14 +266,18 @@ class SlabCrate:
         self.backend.set_slab(self.lo, self.hi, HALO_COLUMNS, self.left is not None, self.right is not None)
         self._own_mask = own
         self.backend.load(p[own], v[own], ids)
-        self._host_staged = dist.is_initialized() and dist.get_backend(group) != "nccl"
+        self.halo_capacity = int(halo_capacity)
+        self._initial_slabs = list(self.slabs)
+        self._now = None      # inputs of the coming tick, when the previous one promised them
+        self._sizes = None    # message sizes of the coming exchange
+        self._host_staged = not self._chained and dist.is_initialized() and dist.get_backend(group) != "nccl"
         self._stage = {}
-        self._ops = None
-        self.transport = "torch"
+        self.transport = "chain" if self._chained else "torch"
         want = (transport or os.environ.get("SANDCRATE_TRANSPORT", "rccl")).lower()
         if want not in ("rccl", "torch"):
             raise ValueError("transport must be 'rccl' or 'torch'")
-        if want == "rccl" and self.world > 1 and not self._host_staged and hasattr(self.backend, "exchange_rccl"):
+        if (want == "rccl" and self.world > 1 and not self._chained and not self._host_staged
+                and hasattr(self.backend, "exchange_rccl")):
             self._try_rccl()
 
     def reload(self, particles, velocities) -> None:
@@ -215,6 +292,9 @@ class SlabCrate:
         self.rigid_bodies = build_rigid_bodies(self.world_config.rigid_bodies)
         self._pad_cache = {}
         self.tick = 0
+        self._now = None
+        if self.slabs != self._initial_slabs:
+            self._apply_cuts(self._initial_slabs)
         own = self._own_mask
         self.backend.load(p[own], v[own], np.flatnonzero(own).astype(np.int64))
         for name in ("packed_ahead", "_promised", "_inputs", "_params_key"):
@@ -288,25 +368,22 @@ class SlabCrate:
             self.transport = "rccl"
 
     def _exchange(self) -> None:
-        """One message each way with each existing neighbor."""
-        if self.world == 1:
+        """One message each way with each existing neighbor, of the sizes agreed for this tick."""
+        if self.world == 1 or self._chained:
             return
         dist, be = self.dist, self.backend
+        sl, rl, sr, rr = self._sizes
         if self.transport == "rccl":
-            be.exchange_rccl(self.left, self.right)
+            be.exchange_rccl(self.left, self.right, self._sizes)
             return
-        pairs = []  # (peer, send tensor, recv tensor)
+        words = lambda records: (records + 1) * HALO_FIELDS  # noqa: E731  (+ the header record)
+        pairs = []  # (peer, what to send, where to receive)
         if self.left is not None:
-            pairs.append((self.left, be.send_left, be.recv_left))
+            pairs.append((self.left, be.send_left[:words(sl)], be.recv_left[:words(rl)]))
         if self.right is not None:
-            pairs.append((self.right, be.send_right, be.recv_right))
+            pairs.append((self.right, be.send_right[:words(sr)], be.recv_right[:words(rr)]))
         if self._host_staged:
-            staged = []
-            for peer, send, recv in pairs:
-                key = (peer, "r")
-                if key not in self._stage:
-                    self._stage[key] = send.new_empty(send.shape, device="cpu")
-                staged.append((peer, send.to("cpu"), self._stage[key], recv))
+            staged = [(peer, send.to("cpu"), torch_empty_like_cpu(recv), recv) for peer, send, recv in pairs]
             ops = []
             for peer, s_cpu, r_cpu, _ in staged:
                 ops.append(dist.P2POp(dist.isend, s_cpu, peer, self.group))
@@ -316,41 +393,94 @@ class SlabCrate:
             for _, _, r_cpu, recv in staged:
                 recv.copy_(r_cpu)
         else:
-            if self._ops is None:  # the same buffers and peers every tick
-                self._ops = []
-                for peer, send, recv in pairs:
-                    self._ops.append(dist.P2POp(dist.isend, send, peer, self.group))
-                    self._ops.append(dist.P2POp(dist.irecv, recv, peer, self.group))
-            for work in dist.batch_isend_irecv(self._ops):
+            ops = []
+            for peer, send, recv in pairs:
+                ops.append(dist.P2POp(dist.isend, send, peer, self.group))
+                ops.append(dist.P2POp(dist.irecv, recv, peer, self.group))
+            for work in dist.batch_isend_irecv(ops):
                 work.wait()  # stream-ordered for NCCL: the current stream waits, the host does not
 
-    def run(self, n_ticks: int) -> None:
+    # -- one tick in phases (SlabChain interleaves them across its members)
+    def _rebalance_due(self, tick: int) -> bool:
+        return self.rebalance_every > 0 and self.world > 1 and tick > 0 and tick % self.rebalance_every == 0
+
+    def _histogram_window(self) -> tuple[int, int]:
+        """Columns of the region particles live in, [-r, 1 + r] (crate.py:152), with the wall-fix margin."""
+        d, r = self.particle_radius * 2, self.particle_radius
+        col0 = int(math.floor(-r / d)) - 3
+        return col0, int(math.floor((1 + r) / d)) + 3 - col0 + 1
+
+    def _apply_cuts(self, slabs) -> None:
+        self.slabs = list(slabs)
+        self.lo, self.hi = self.slabs[self.rank]
+        self.backend.set_slab(self.lo, self.hi, HALO_COLUMNS, self.left is not None, self.right is not None)
+
+    def _begin_tick(self) -> None:
+        """The coming tick's inputs go to the backend (the grid the halo kernels use depends on them)."""
+        if self._now is None:
+            for body in self.rigid_bodies:
+                body.apply_velocity(self.dt)
+            self._now = self._tick_inputs()
+        self.backend.set_tick_inputs(*self._now)
+
+    def _rebalance(self, global_hist=None) -> bool:
+        """On schedule: new cuts from the global column histogram (one small all-reduce).  -> cuts changed."""
+        if not self._rebalance_due(self.tick):
+            return False
+        col0, ncols = self._histogram_window()
+        if global_hist is None:
+            import torch
+            hist = torch.from_numpy(self.backend.column_histogram(col0, ncols))
+            if not self._host_staged:
+                hist = hist.to(self.backend.device)
+            self.dist.all_reduce(hist, group=self.group)
+            global_hist = hist.cpu().numpy()
+        # what may change owner in one go: the message capacity minus what the band itself needs
+        budget = max(0, self.halo_capacity // 2)
+        new = rebalanced_cuts(np.asarray(global_hist, dtype=np.int64), col0, self.slabs, budget)
+        if new == self.slabs:
+            return False
+        self._apply_cuts(new)
+        self.rebalances += 1
+        return True
+
+    def _pack(self, whole_messages: bool) -> None:
+        if self.world == 1:
+            return
+        # a backend that was promised this tick's inputs packed its halo message at the end of the previous
+        # tick (HipSlabBackend: in the force kernel's epilogue)
+        if not getattr(self.backend, "packed_ahead", False):
+            self.backend.pack()
+        self._sizes = self.backend.message_sizes(whole=whole_messages)
+
+    def _end_tick(self, promise_next: bool) -> None:
         be = self.backend
-        now = None
+        if self.world > 1:
+            be.unpack(self.left is not None, self.right is not None, self._sizes)
+        nxt = None
+        for body in self.rigid_bodies:  # crate.py:311-314: this tick's gravity step on free bodies
+            if body.moves and not body.driven:
+                body.center_velocity = body.center_velocity + self.dt * self.gravity
+        if promise_next:  # nobody can edit coefficients inside run(): the next tick's inputs are known
+            for body in self.rigid_bodies:
+                body.apply_velocity(self.dt)
+            nxt = self._tick_inputs()
+        be.step(nxt)
+        self.tick += 1
+        self._now = nxt
+
+    def _may_promise(self, k: int, n_ticks: int) -> bool:
+        # a tick that re-balances packs its message itself, after the cuts are known: its predecessor must not
+        return k + 1 < n_ticks and not self._rebalance_due(self.tick + 1)
+
+    def run(self, n_ticks: int) -> None:
+        if self._chained:
+            raise RuntimeError("a chain member is stepped by its SlabChain")
         for k in range(n_ticks):
-            if now is None:
-                for body in self.rigid_bodies:
-                    body.apply_velocity(self.dt)
-                now = self._tick_inputs()
-            be.set_tick_inputs(*now)
-            if self.world > 1:
-                # a backend that was promised this tick's inputs packed its halo message at the end of the
-                # previous tick (HipSlabBackend: in the force kernel's epilogue)
-                if not getattr(be, "packed_ahead", False):
-                    be.pack()
-                self._exchange()
-                be.unpack(self.left is not None, self.right is not None)
-            nxt = None
-            for body in self.rigid_bodies:  # crate.py:311-314: this tick's gravity step on free bodies
-                if body.moves and not body.driven:
-                    body.center_velocity = body.center_velocity + self.dt * self.gravity
-            if k + 1 < n_ticks:  # nobody can edit coefficients inside run(): the next tick's inputs are known
-                for body in self.rigid_bodies:
-                    body.apply_velocity(self.dt)
-                nxt = self._tick_inputs()
-            be.step(nxt)
-            self.tick += 1
-            now = nxt
+            self._begin_tick()
+            self._pack(whole_messages=self._rebalance())
+            self._exchange()
+            self._end_tick(self._may_promise(k, n_ticks))
 
     def physics_tick(self) -> None:
         self.run(1)
@@ -389,3 +519,72 @@ class SlabCrate:
         ids = np.concatenate([x[3] for x in parts])
         order = np.argsort(ids, kind="stable")
         return p[order], v[order], pr[order], ids[order]
+
+
+class SlabChain:
+    """All slabs of a domain in ONE process on ONE GPU: `n_slabs` chain members (each its own library context),
+    halo messages moved by device-to-device copies, histograms added on the host.  The same code path as one
+    process per GPU except for the transport -- what the tests use to run the multi-GPU configurations of
+    BASELINE.json on a one-GPU box, bit-equal to the single-domain run."""
+
+    def __init__(self, world_config, particles, velocities, n_slabs: int, *, device: int = 0, noise: str = "counter",
+                 noise_seed: int = 0, halo_capacity: int | None = None, capacity: int | None = None,
+                 rebalance_every: int = 0, cuts: list[int] | None = None, backend_factory=None):
+        self.members = []
+        for k in range(n_slabs):
+            backend = backend_factory(k) if backend_factory is not None else None
+            self.members.append(SlabCrate(copy.deepcopy(world_config), particles, velocities, device=device, noise=noise,
+                                          noise_seed=noise_seed, halo_capacity=halo_capacity, capacity=capacity,
+                                          rebalance_every=rebalance_every, cuts=cuts, rank=k, world=n_slabs,
+                                          backend=backend))
+        self.tick = 0
+        self.message_records = []  # per tick: the records every message carried (left-to-right, then right-to-left)
+
+    @property
+    def slabs(self):
+        return self.members[0].slabs
+
+    def _move_messages(self) -> None:
+        words = lambda records: (records + 1) * HALO_FIELDS  # noqa: E731
+        sent = []
+        for a, b in zip(self.members[:-1], self.members[1:]):
+            to_right, from_left = a._sizes[2], b._sizes[1]
+            to_left, from_right = b._sizes[0], a._sizes[3]
+            if to_right != from_left or to_left != from_right:
+                raise RuntimeError(f"slabs {a.rank} and {b.rank} disagree on their message sizes: "
+                                   f"{to_right} vs {from_left}, {to_left} vs {from_right}")
+            b.backend.recv_left[:words(to_right)].copy_(a.backend.send_right[:words(to_right)])
+            a.backend.recv_right[:words(to_left)].copy_(b.backend.send_left[:words(to_left)])
+            sent += [to_right, to_left]
+        self.message_records.append(sent)
+
+    def run(self, n_ticks: int) -> None:
+        ms = self.members
+        for k in range(n_ticks):
+            for m in ms:
+                m._begin_tick()
+            changed = False
+            if ms[0]._rebalance_due(ms[0].tick):
+                col0, ncols = ms[0]._histogram_window()
+                hist = sum(m.backend.column_histogram(col0, ncols) for m in ms)
+                changed = [m._rebalance(hist) for m in ms][0]
+            for m in ms:
+                m._pack(whole_messages=changed)
+            self._move_messages()
+            promise = ms[0]._may_promise(k, n_ticks)
+            for m in ms:
+                m._end_tick(promise)
+            self.tick += 1
+
+    def synchronize(self) -> None:
+        for m in self.members:
+            m.synchronize()
+
+    def owned_counts(self) -> list[int]:
+        return [m.backend.owned_count() for m in self.members]
+
+    def gather_state(self):
+        parts = [m.owned_state() for m in self.members]
+        ids = np.concatenate([x[3] for x in parts])
+        order = np.argsort(ids, kind="stable")
+        return tuple(np.concatenate([x[k] for x in parts])[order] for k in range(4))

@@ -47,7 +47,14 @@ class OracleSlabBackend:
         self._fill(self.send_left, (col < self.lo + self.halo) if self.has_left else np.zeros(len(col), bool))
         self._fill(self.send_right, (col >= self.hi - self.halo) if self.has_right else np.zeros(len(col), bool))
 
-    def unpack(self, from_left, from_right):
+    def message_sizes(self, whole=False):
+        return (self.cap,) * 4  # the lagged sizes are the library's business (sc_halo_sizes); here: whole buffers
+
+    def column_histogram(self, col0, n_columns):
+        col = column_of(self.p[:, 0], 2 * self.coef["particle_radius"])
+        return np.bincount(np.clip(col - col0, 0, n_columns - 1), minlength=n_columns).astype(np.int64)
+
+    def unpack(self, from_left, from_right, sizes=None):
         for use, tensor in ((from_left, self.recv_left), (from_right, self.recv_right)):
             if not use:
                 continue
@@ -65,6 +72,10 @@ class OracleSlabBackend:
         own = (col >= self.lo) & (col < self.hi)
         keep = own | ((col >= self.lo - self.halo) & (col < self.hi + self.halo))
         p, v, ids, own = p[keep], v[keep], ids[keep], own[keep]
+        # the reference breaks ties of equal x by array position (stable lexsort, collision_detector.py:127), which in
+        # the single domain is the particle id: keep the local arrays in id order (the HIP path sorts by id explicitly)
+        order = np.argsort(ids, kind="stable")
+        p, v, ids, own = p[order], v[order], ids[order], own[order]
         eta = None if self.noise == "none" else counter_noise_u01(ids, counter_noise_key(self.seed, self.tick))
         out = tick_core(p, v, self.segments, self.bodies, c, eta_u01=eta)
         self.p, self.v, self.ids = out["particles"][own], out["velocities"][own], ids[own]

