@@ -250,6 +250,25 @@ int sc_halo_exchange(sc_ctx* ctx, const double* send_left, int64_t send_left_rec
                      int64_t recv_left_records, int32_t left_rank, const double* send_right, int64_t send_right_records,
                      double* recv_right, int64_t recv_right_records, int32_t right_rank);
 
+/* NumPy's legacy global generator on the device (the reference draws particle sources and collider noise from
+ * `np.random`, seeded in Crate.__init__, crate.py:22).  sc_rng_set_state hands the stream to the context -- the
+ * 624-word key and the position of `np.random.get_state()` -- and from then on
+ *   sc_emit_particles  runs ParticleSource.generate_particles (particle_source.py:17-24) for the given sources
+ *                      on the device: binomial(flow, dt) new particles each (legacy inversion branch; SC_ERR_DOMAIN
+ *                      if flow * dt > 30 or dt > 0.5), rand(n, 2) position jitter, rand(n, 2) velocity noise,
+ *                      capped at max_particles minus the stored count, appended with the next ids;
+ *   sc_step_finish     in SC_NOISE_HOST mode without a sc_set_noise_host call draws the tick's rand(sum C_i, 2)
+ *                      block on the device,
+ * bit for bit the numbers NumPy would have produced, with no count readback and no upload.  sc_rng_get_state
+ * (synchronises) returns the stream to the host, e.g. for `np.random.set_state`. */
+typedef struct sc_source {
+  double radius, position_x, position_y, velocity_x, velocity_y, noise;
+  int64_t flow;
+} sc_source;
+int sc_rng_set_state(sc_ctx* ctx, const uint32_t* key_624, int32_t position);
+int sc_rng_get_state(sc_ctx* ctx, uint32_t* key_624, int32_t* position);
+int sc_emit_particles(sc_ctx* ctx, const sc_source* sources, int32_t n_sources, double dt, int64_t max_particles);
+
 /* Synchronises.  Live particles stored in this context (dead ghost copies excluded); summed over
  * the ranks this is the global particle count. */
 int sc_owned_count(sc_ctx* ctx, int64_t* n);

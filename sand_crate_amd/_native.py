@@ -16,6 +16,7 @@ MAX_SEGMENTS = 16
 MAX_BODIES = 8
 NUM_KERNELS = 12
 NOISE_NONE, NOISE_HOST, NOISE_COUNTER = 0, 1, 2
+ERR_CAPACITY = -3
 ERR_DOMAIN = -5
 
 
@@ -40,6 +41,11 @@ class Body(C.Structure):
 class TickInputs(C.Structure):
     _fields_ = [("params", Params), ("segments", C.POINTER(C.c_double)), ("padded", C.POINTER(C.c_double)),
                 ("bodies", C.POINTER(Body)), ("n_segments", C.c_int32), ("n_bodies", C.c_int32)]
+
+
+class Source(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("radius", "position_x", "position_y", "velocity_x", "velocity_y", "noise")] + [
+        ("flow", C.c_int64)]
 
 
 class Stats(C.Structure):
@@ -96,6 +102,9 @@ SIGNATURES = {
     "sc_comm_destroy": (C.c_int, [_P]),
     "sc_halo_exchange": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P, C.c_int64, _P, C.c_int64, C.c_int32]),
     "sc_owned_count": (C.c_int, [_P, _I64]),
+    "sc_rng_set_state": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int32]),
+    "sc_rng_get_state": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
+    "sc_emit_particles": (C.c_int, [_P, C.POINTER(Source), C.c_int32, C.c_double, C.c_int64]),
 }
 
 _lib = None

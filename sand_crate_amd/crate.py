@@ -17,10 +17,15 @@ GPU    everything per particle: removal, wall contacts + hard wall fix, strip so
        ``particles`` / ``particle_velocities`` / ``particles_pressure`` attributes download
        lazily, once per tick, when read.
 
-Collider noise (crate.py:169) has three modes:
-``"host"``    (default) the host draws ``rand(sum C_i, 2)`` from the global MT19937 stream each
-              tick, exactly the numbers the reference draws particle by particle -- costs one
-              device->host count and one upload per tick;
+Collider noise (crate.py:169) and particle sources (particle_source.py:17-24) draw from NumPy's global MT19937
+stream in the reference.  Modes:
+``"host"``    (default) that very stream, bit for bit, generated ON THE DEVICE: `Crate.__init__` seeds
+              ``np.random`` like the reference (crate.py:22) and hands the state to the library
+              (sc_rng_set_state); sources and noise are then drawn by kernels (sc_rng.h) and a tick costs no
+              readback, no host draw and no upload.  `sync_host_rng()` returns the stream to ``np.random``
+              for callers that draw from it themselves between ticks.  A source outside the inversion branch
+              of NumPy's legacy binomial (flow * dt > 30) makes the crate fall back to
+``"host-sync"`` the same numbers drawn by the host: one device->host count and one upload per tick;
 ``"counter"`` a counter-based hash on the device keyed by (seed, tick, particle id, slot): same
               distribution, different numbers, no host round trip (used for throughput runs);
 ``"none"``    no noise (what ``collider_noise_level = 0`` computes).
@@ -41,7 +46,7 @@ from .particle_source import build_particle_sources
 from .rigid_body import build_rigid_bodies
 from .utils.geometry_utils import pad_segments
 
-_NOISE_MODES = {"none": N.NOISE_NONE, "host": N.NOISE_HOST, "counter": N.NOISE_COUNTER}
+_NOISE_MODES = {"none": N.NOISE_NONE, "host": N.NOISE_HOST, "host-sync": N.NOISE_HOST, "counter": N.NOISE_COUNTER}
 _TICK_COEFFICIENTS = ("dt", "particle_radius", "wall_collision_decay", "pressure_amplifier", "ignored_pressure",
                       "collider_noise_level", "viscosity", "surface_smoothing", "target_pressure")
 
@@ -87,6 +92,8 @@ class Crate:
         self._noise = noise
         self._noise_seed = noise_seed
         self._engine.set_noise_mode(_NOISE_MODES[noise], noise_seed)
+        if noise == "host":        # the device takes over the global stream the reference draws from
+            self._hand_rng_to_device()
         self._count = 0            # particles on the device after the last tick / upload
         self._count_known = True
         self._cache = None         # (particles, velocities, pressure) downloaded for this tick
@@ -117,6 +124,9 @@ class Crate:
         return self._count
 
     # ------------------------------------------------------------------ state attributes
+    def _count_or_unknown(self) -> bool:
+        return (not self._count_known) or self._count > 0
+
     def _empty(self) -> None:
         self._cache = (np.zeros((0, 2)), np.zeros((0, 2)), np.zeros((0,)))
 
@@ -162,11 +172,33 @@ class Crate:
         self._cache = (particles, velocities, np.zeros(len(particles)))
         self._count, self._count_known = len(particles), True
 
+    def _hand_rng_to_device(self) -> None:
+        name, key, pos, _, _ = np.random.get_state()
+        if name != "MT19937":
+            raise RuntimeError("np.random is not the legacy MT19937 generator")
+        self._engine.rng_set_state(key, pos)
+
+    def sync_host_rng(self) -> None:
+        """noise="host": bring ``np.random`` to where the device stream stands (synchronises).  The device keeps
+        drawing from its own copy afterwards: call this before host code draws from the global generator, and
+        `_hand_rng_to_device()` happens again on the next tick if the host state moved."""
+        if self._noise == "host":
+            key, pos = self._engine.rng_get_state()
+            np.random.set_state(("MT19937", key, pos, 0, 0.0))
+            self._host_rng_mark = (key.copy(), pos)
+
+    def _fall_back_to_host_stream(self) -> None:
+        self.sync_host_rng()
+        self._noise = "host-sync"
+
     def _grow(self, needed: int) -> None:
-        p, v, _ = self._state() if self._count else (np.zeros((0, 2)), np.zeros((0, 2)), None)
+        p, v, _ = self._state() if self._count_or_unknown() else (np.zeros((0, 2)), np.zeros((0, 2)), None)
         old = self._engine
+        rng = old.rng_get_state() if self._noise == "host" else None
         self._engine = Engine(int(needed * 1.5) + 1024, device=old.device)
         self._engine.set_noise_mode(_NOISE_MODES[self._noise], self._noise_seed)
+        if rng is not None:
+            self._engine.rng_set_state(*rng)
         old.close()
         if len(p):
             self._engine.upload(p, v)
@@ -180,7 +212,12 @@ class Crate:
             body.apply_velocity(self.dt)
         self._send_tick_inputs()
         eng = self._engine
-        if self._noise == "host":
+        if self._noise == "host":    # the stream lives on the device: nothing comes back, nothing goes up
+            eng.step_begin()
+            eng.step_finish()
+            self._count_known = False
+            self.last_stats = None
+        elif self._noise == "host-sync":
             eng.step_begin()
             stats = eng.step_stats()
             self.last_stats = stats
@@ -217,7 +254,7 @@ class Crate:
     def run(self, n_ticks: int) -> None:
         """`n_ticks` ticks back to back without touching the host state in between (no sources
         may be active, noise must not be "host"): the throughput path bench.py measures."""
-        if self._noise == "host":
+        if self._noise in ("host", "host-sync"):
             raise RuntimeError("Crate.run needs noise='counter' or 'none'")
         if any(src.active_ticks > self.tick for src in self.particle_sources):
             raise RuntimeError("Crate.run cannot interleave particle sources; use physics_tick()")
@@ -256,6 +293,31 @@ class Crate:
 
     def _create_new_particles(self) -> None:
         """crate.py:138-147: sources append in order, each seeing the count the previous left."""
+        if self._noise == "host":
+            active = [s for s in self.particle_sources if s.active_ticks > self.tick]
+            if not active:
+                return
+            mark = getattr(self, "_host_rng_mark", None)
+            if mark is not None:  # sync_host_rng() was used: has the host drawn from the stream since?
+                _, key, pos, _, _ = np.random.get_state()
+                if pos != mark[1] or not np.array_equal(key, mark[0]):
+                    self._hand_rng_to_device()
+                self._host_rng_mark = None
+            try:
+                self._engine.emit_particles(active, self.dt, int(self.max_particles))
+                self._cache = None
+                self._count_known = False
+                return
+            except N.NativeError as err:
+                if err.code == N.ERR_CAPACITY:
+                    self._grow(max(self._engine.capacity, int(self.max_particles)) + 1024)
+                    self._engine.emit_particles(active, self.dt, int(self.max_particles))
+                    self._cache = None
+                    self._count_known = False
+                    return
+                if err.code != N.ERR_DOMAIN:
+                    raise
+                self._fall_back_to_host_stream()  # binomial outside the inversion branch: the host draws from here on
         for source in self.particle_sources:
             if source.active_ticks <= self.tick:
                 continue

@@ -19,6 +19,7 @@
 #include "sandcrate_hip.h"
 #include "sc_kernels.h"
 #include "sc_rccl.h"
+#include "sc_rng.h"
 #include "sc_tiled.h"
 
 using namespace sc;
@@ -88,6 +89,7 @@ struct sc_ctx {
   double *haloL = nullptr, *haloR = nullptr;  // send buffers of the last sc_halo_pack (caller-owned device memory)
   int haloCap = 0;
   int64_t halo_ring_from = 0;  // first tick whose halo counts in the progress block belong to the current state
+  RngState* rng = nullptr;     // NumPy's MT19937 stream on the device (sc_rng_set_state), or null
   int* colHist = nullptr;      // sc_column_histogram
   int64_t colHistAlloc = 0;
   int* rankAcc = nullptr;  // per bucket slot: rank inside a big bucket (k_rank_big adds, k_reorder takes and clears)
@@ -400,10 +402,10 @@ int put_particles(sc_ctx* c, const double* xy, const double* vxy, int64_t n, boo
     hipLaunchKernelGGL(k_append, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, c->stage_xy, c->stage_vxy, (int)n,
                        (int)c->next_id, dev_ids, c->counters, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], reset ? 1 : 0);
   }
-  hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, c->stream, c->counters, (int)n, reset ? 1 : 0);
-  HIPCHK(hipGetLastError());
   c->upper = base + n;
   c->next_id += n;
+  hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, c->stream, c->counters, (int)n, reset ? 1 : 0, (int)c->next_id);
+  HIPCHK(hipGetLastError());
   return SC_OK;
 }
 
@@ -533,7 +535,7 @@ int sc_destroy(sc_ctx* c) {
   }
   void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->rankAcc, c->wrec[0], c->wrec[1],
                   c->nbr, c->nbr16, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
-                  c->stage_xy, c->stage_vxy, c->stage_ids, c->owned_out, c->colHist};
+                  c->stage_xy, c->stage_vxy, c->stage_ids, c->owned_out, c->colHist, c->rng};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& v : {c->ev_used, c->ev_free})
@@ -761,8 +763,25 @@ int sc_set_noise_host(sc_ctx* c, const double* u01, int64_t n_pairs) {
 int sc_step_finish(sc_ctx* c) {
   if (!c) return fail(SC_ERR_ARG, "null context");
   if (!c->in_step) return fail(SC_ERR_STATE, "sc_step_finish needs sc_step_begin first");
-  if (c->noise_mode == SC_NOISE_HOST && c->etaPairs < 0)
-    return fail(SC_ERR_STATE, "SC_NOISE_HOST: sc_set_noise_host must be called every tick");
+  if (c->noise_mode == SC_NOISE_HOST && c->etaPairs < 0) {
+    if (!c->rng) return fail(SC_ERR_STATE, "SC_NOISE_HOST: sc_set_noise_host must be called every tick (or sc_rng_set_state once)");
+    // the device holds the stream: draw the tick's rand(sum C_i, 2) there; sum C_i is the last entry of the
+    // offsets sc_step_begin scanned, so the host never learns it
+    const int64_t room = (int64_t)kMaxNbr * c->cap;
+    if (room > c->etaAlloc) {
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (c->eta) (void)hipFree(c->eta);
+      c->eta = nullptr;
+      HIPCHK(dalloc(&c->eta, 2 * (size_t)room));
+      c->etaAlloc = room;
+    }
+    if (c->next_id > 0) {
+      Bracket br(c, K_NOISE_OFFSETS);
+      hipLaunchKernelGGL(k_rng_noise, dim3(1), dim3(kRngBlock), 0, c->stream, c->rng, c->offById + c->next_id, c->eta,
+                         (long long)c->etaAlloc, c->counters);
+    }
+    c->etaPairs = 0;
+  }
   // look-ahead: run K1 of the next tick in pass B's epilogue.  Slabs: pass B also packs the next halo
   // message into the buffers of the last sc_halo_pack, and sc_halo_unpack does K1 for what it appends.
   WallInputs wn;
@@ -1320,6 +1339,86 @@ int sc_owned_count(sc_ctx* c, int64_t* n) {
   HIPCHK(hipMemcpyAsync(&h, c->owned_out, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   *n = h;
+  return SC_OK;
+}
+
+// ---- NumPy's global MT19937 stream on the device (sc_rng.h) -------------------------------------
+
+int sc_rng_set_state(sc_ctx* c, const uint32_t* key, int32_t pos) {
+  if (!c || !key || pos < 0 || pos > kMtN) return fail(SC_ERR_ARG, "an MT19937 state is 624 words and a position in [0, 624]");
+  if (c->in_step) return fail(SC_ERR_STATE, "the generator cannot change inside a tick");
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->rng) HIPCHK(dalloc(&c->rng, 1));
+  RngState h;
+  std::memcpy(h.mt, key, sizeof h.mt);
+  h.pos = pos;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(c->rng, &h, sizeof h, hipMemcpyHostToDevice));
+  return SC_OK;
+}
+
+int sc_rng_get_state(sc_ctx* c, uint32_t* key, int32_t* pos) {
+  if (!c || !key || !pos) return fail(SC_ERR_ARG, "null argument");
+  if (!c->rng) return fail(SC_ERR_STATE, "sc_rng_set_state has not been called");
+  if (c->in_step) return fail(SC_ERR_STATE, "sc_rng_get_state inside a tick");
+  RngState h;
+  HIPCHK(hipMemcpyAsync(&h, c->rng, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::memcpy(key, h.mt, sizeof h.mt);
+  *pos = h.pos;
+  return SC_OK;
+}
+
+int sc_emit_particles(sc_ctx* c, const sc_source* sources, int32_t n_sources, double dt, int64_t max_particles) {
+  if (!c || n_sources < 0 || (n_sources > 0 && !sources)) return fail(SC_ERR_ARG, "bad sources");
+  if (!c->rng) return fail(SC_ERR_STATE, "sc_rng_set_state has not been called");
+  if (c->in_step) return fail(SC_ERR_STATE, "particles cannot change between sc_step_begin and sc_step_finish");
+  if (c->prebinned) return fail(SC_ERR_STATE, "particles cannot be emitted after sc_set_next_inputs promised the next tick");
+  if (n_sources > kMaxSources) return fail(SC_ERR_CAPACITY, "%d particle sources, at most %d", n_sources, kMaxSources);
+  if (n_sources == 0) return SC_OK;
+  SourcesK k;
+  std::memset(&k, 0, sizeof k);
+  k.n = n_sources;
+  int64_t most = 0;
+  for (int i = 0; i < n_sources; ++i) {
+    const sc_source& s = sources[i];
+    const double p = dt;
+    // the legacy binomial takes this branch for p <= 0.5 and n p <= 30 (both YAML scenes: n p = 4 and 14)
+    if (!(p > 0.0 && p <= 0.5) || s.flow < 1 || (double)s.flow * p > 30.0)
+      return fail(SC_ERR_DOMAIN, "binomial(%lld, %g) is outside the inversion branch of NumPy's legacy generator",
+                  (long long)s.flow, p);
+    SourceK& d = k.src[i];
+    d.radius = s.radius; d.px = s.position_x; d.py = s.position_y; d.vx = s.velocity_x; d.vy = s.velocity_y;
+    d.noise = s.noise; d.flow = s.flow; d.p = p;
+    d.q = 1.0 - p;
+    d.qn = std::exp((double)s.flow * std::log(d.q));
+    const double np_ = (double)s.flow * p;
+    d.bound = (long long)std::min((double)s.flow, np_ + 10.0 * std::sqrt(np_ * d.q + 1));
+    most += d.bound;
+  }
+  // host-side bounds of the stored count and of the ids: at most `bound` particles per source; the live count a
+  // recent tick published (progress block) keeps the bound from drifting away without any synchronisation
+  const int64_t done = *(volatile int*)(c->bigHintHost + 1), live = *(volatile int*)(c->bigHintHost + 2);
+  int64_t upper = c->upper + most;
+  if (done > 0 && c->tick >= done && c->tick - done <= 8) upper = std::min(upper, live + (c->tick - done + 1) * most);
+  upper = std::min<int64_t>(upper, std::max<int64_t>(max_particles, c->upper));
+  if (upper > c->cap) {
+    int h[C_COUNT];
+    int rc = read_counters(c, h);  // rare: the bound reached the capacity, look at the real count
+    if (rc) return rc;
+    upper = std::min<int64_t>(h[C_NS] + most, std::max<int64_t>(max_particles, h[C_NS]));
+    if (upper > c->cap) return fail(SC_ERR_CAPACITY, "%lld particles may exceed the context capacity %lld", (long long)upper, (long long)c->cap);
+  }
+  if (c->next_id + most > std::numeric_limits<int>::max()) return fail(SC_ERR_CAPACITY, "particle ids exhausted");
+  HIPCHK(hipSetDevice(c->device));
+  {
+    Bracket br(c, K_APPEND);
+    hipLaunchKernelGGL(k_rng_emit, dim3(1), dim3(64), 0, c->stream, k, (long long)max_particles, c->rng, c->counters, c->x[0],
+                       c->y[0], c->vx[0], c->vy[0], c->id[0], (int)c->cap);
+  }
+  HIPCHK(hipGetLastError());
+  c->upper = upper;
+  c->next_id += most;  // an upper bound from here on: the device counts the ids it hands out (C_NEXT_ID)
   return SC_OK;
 }
 

@@ -80,7 +80,7 @@ enum Counter {
   C_SUMC = 4,   // sum of neighbor counts (low 32 bits)
   C_MAXC = 5,   // max neighbor count
   C_SUMC_HI = 6,
-  C_SPARE7 = 7,  // (unused)
+  C_NEXT_ID = 7,  // id the next emitted particle gets (k_rng_emit counts on the device; uploads set it)
   C_SPARE8 = 8,
   C_TICKET = 9,  // workgroups that have finished the current halo kernel (last one publishes / bumps)
   C_NBIG = 10,   // buckets above kSortThreshold listed this tick

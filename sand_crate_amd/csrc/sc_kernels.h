@@ -41,7 +41,10 @@ __global__ void k_append(const double* __restrict__ xy, const double* __restrict
   // separate one-thread launch (k_bump) ordered after this kernel on the stream.
 }
 
-__global__ void k_bump(int* counters, int m, int reset) { counters[C_NS] = (reset ? 0 : counters[C_NS]) + m; }
+__global__ void k_bump(int* counters, int m, int reset, int next_id) {
+  counters[C_NS] = (reset ? 0 : counters[C_NS]) + m;
+  counters[C_NEXT_ID] = next_id;  // the host's id counter after this append (an upper bound once the device emits)
+}
 
 // ------------------------------------------------------------------------------------------
 // K1  wall + bin.  One thread per stored particle.

@@ -1,0 +1,185 @@
+// NumPy's legacy global generator on the device: MT19937 with NumPy's state layout
+// (624-word key + position), `random_sample` doubles, and what the tick draws from it --
+//   k_rng_emit   ParticleSource.generate_particles (particle_source.py:17-24) for every active source: the
+//                inversion branch of the legacy binomial, then rand(n, 2) for the position jitter and rand(n, 2)
+//                for the velocity noise, appended to the storage arrays (crate.py:138-147);
+//   k_rng_noise  the tick's collider noise (crate.py:169): one block rand(sum C_i, 2), which is what the reference
+//                draws particle by particle (`rand(a, 2)` then `rand(b, 2)` is `rand(a + b, 2)` split).
+// The stream is NumPy's bit for bit (oracle/rng.py restates it and is checked against np.random), so the default
+// noise="host" mode of `Crate` needs no per-tick count readback, host draw and upload any more.  Included once by
+// sandcrate_hip.hip after sc_kernels.h.  Built with -ffp-contract=off like everything else: the position and
+// velocity arithmetic is NumPy's, operation for operation.
+#pragma once
+#include "sc_kernels.h"
+
+namespace sc {
+
+constexpr int kMtN = 624, kMtM = 397;
+constexpr uint32_t kMtUpper = 0x80000000u, kMtLower = 0x7FFFFFFFu, kMtA = 0x9908B0DFu;
+
+struct RngState {
+  uint32_t mt[kMtN];
+  int pos;  // next unused word of mt; kMtN: the block is used up
+};
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9D2C5680u;
+  y ^= (y << 15) & 0xEFC60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+__device__ __forceinline__ uint32_t mt_twist(uint32_t cur, uint32_t next, uint32_t far) {
+  const uint32_t y = (cur & kMtUpper) | (next & kMtLower);
+  return far ^ (y >> 1) ^ ((y & 1u) ? kMtA : 0u);
+}
+
+__device__ __forceinline__ double mt_double(uint32_t a, uint32_t b) {  // NumPy: (a >> 5, b >> 6)
+  return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+
+// one thread, state in global memory: the few dozen draws of the particle sources
+struct RngSerial {
+  RngState* s;
+  __device__ uint32_t next_u32() {
+    if (s->pos >= kMtN) {
+      uint32_t* mt = s->mt;
+      for (int kk = 0; kk < kMtN; ++kk) mt[kk] = mt_twist(mt[kk], mt[(kk + 1) % kMtN], mt[(kk + kMtM) % kMtN]);
+      s->pos = 0;
+    }
+    return mt_temper(s->mt[s->pos++]);
+  }
+  __device__ double next_double() {
+    const uint32_t a = next_u32(), b = next_u32();
+    return mt_double(a, b);
+  }
+};
+
+struct SourceK {
+  double radius, px, py, vx, vy, noise;
+  double p, q, qn;          // binomial(flow, p): p = dt, q = 1 - p, qn = q^flow as exp(flow log q) (host libm, like NumPy)
+  long long flow, bound;    // restart bound min(flow, flow p + 10 sqrt(flow p q + 1))
+};
+constexpr int kMaxSources = 8;
+struct SourcesK {
+  SourceK src[kMaxSources];
+  int n;
+};
+
+// crate.py:138-147 + particle_source.py:17-24.  One thread: a tick emits a handful of particles.
+__global__ void k_rng_emit(SourcesK srcs, long long max_particles, RngState* __restrict__ state, int* __restrict__ counters,
+                           double* __restrict__ x, double* __restrict__ y, double* __restrict__ vx,
+                           double* __restrict__ vy, int* __restrict__ id, int cap) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  RngSerial rng{state};
+  int stored = counters[C_NS];
+  int next_id = counters[C_NEXT_ID];
+  for (int k = 0; k < srcs.n; ++k) {
+    const SourceK s = srcs.src[k];
+    // legacy random_binomial_inversion
+    long long X = 0;
+    double px = s.qn, U = rng.next_double();
+    while (U > px) {
+      ++X;
+      if (X > s.bound) {
+        X = 0;
+        px = s.qn;
+        U = rng.next_double();
+      } else {
+        U -= px;
+        px = ((double)(s.flow - X + 1) * s.p * px) / ((double)X * s.q);
+      }
+    }
+    long long count = X;  // np.round of an integer
+    const long long room = max_particles - stored;  // crate.py:142: the count the previous source left
+    if (count > room) count = room;
+    if (count <= 0) continue;  // particle_source.py:19-20 (a negative room draws nothing more either)
+    if (stored + count > cap) {
+      atomicOr(&counters[C_FLAGS], F_CAPACITY);
+      count = cap - stored;
+    }
+    for (long long j = 0; j < count; ++j) {  // jitter = rand(count, 2); (jitter - 0.5) * radius + position
+      const double jx = rng.next_double(), jy = rng.next_double();
+      x[stored + j] = (jx - 0.5) * s.radius + s.px;
+      y[stored + j] = (jy - 0.5) * s.radius + s.py;
+    }
+    for (long long j = 0; j < count; ++j) {  // ones * velocity += (rand(count, 2) - 0.5) * noise
+      const double nx = rng.next_double(), ny = rng.next_double();
+      vx[stored + j] = s.vx + (nx - 0.5) * s.noise;
+      vy[stored + j] = s.vy + (ny - 0.5) * s.noise;
+      id[stored + j] = next_id + (int)j;
+    }
+    stored += (int)count;
+    next_id += (int)count;
+  }
+  counters[C_NS] = stored;
+  counters[C_NEXT_ID] = next_id;
+}
+
+// The collider noise of one tick: 2 * pairs doubles from the stream into eta, in order.  One workgroup: a state
+// block of 624 words is regenerated in three dependent phases (the recurrence reaches 227 words back), tempered
+// and turned into doubles by all threads; a double whose two words straddle a block boundary is finished by
+// thread 0 with the carried word.
+constexpr int kRngBlock = 1024;
+__global__ void __launch_bounds__(kRngBlock)
+    k_rng_noise(RngState* __restrict__ state, const int* __restrict__ pairs_ptr, double* __restrict__ eta,
+                long long eta_pairs_room, int* __restrict__ counters) {
+  __shared__ uint32_t mt[kMtN];
+  const int tid = threadIdx.x;
+  for (int k = tid; k < kMtN; k += kRngBlock) mt[k] = state->mt[k];
+  int pos = state->pos;
+  long long pairs = *pairs_ptr;
+  if (pairs > eta_pairs_room) {
+    if (tid == 0) atomicOr(&counters[C_FLAGS], F_CAPACITY);
+    pairs = eta_pairs_room;
+  }
+  const long long need = 2 * pairs;  // doubles
+  long long w = 0;
+  bool have_carry = false;
+  uint32_t carry = 0;
+  __syncthreads();
+  while (w < need) {  // every variable that steers this loop is uniform over the workgroup
+    if (pos >= kMtN) {
+      // kk in [0, 227): old words only; [227, 454): new words of the first phase; [454, 624): of the second
+      // (word 623 also takes the NEW word 0)
+      for (int phase = 0; phase < 3; ++phase) {
+        const int kk = phase * (kMtN - kMtM) + tid;
+        const int end = phase == 2 ? kMtN : (phase + 1) * (kMtN - kMtM);
+        uint32_t v = 0;
+        const bool mine = tid < kMtN - kMtM && kk < end;
+        if (mine) v = mt_twist(mt[kk], mt[(kk + 1) % kMtN], mt[(kk + kMtM) % kMtN]);
+        __syncthreads();
+        if (mine && kk != kMtN - 1) mt[kk] = v;
+        __syncthreads();
+        if (phase == 2 && tid == 0) mt[kMtN - 1] = mt_twist(mt[kMtN - 1], mt[0], mt[kMtM - 1]);
+        __syncthreads();
+      }
+      pos = 0;
+    }
+    int start = pos;
+    if (have_carry) {
+      if (tid == 0) eta[w] = mt_double(carry, mt_temper(mt[start]));
+      w += 1;
+      start += 1;
+      have_carry = false;
+    }
+    const long long left = need - w;
+    const int nd = (int)min((long long)((kMtN - start) / 2), left);
+    for (int k = tid; k < nd; k += kRngBlock)
+      eta[w + k] = mt_double(mt_temper(mt[start + 2 * k]), mt_temper(mt[start + 2 * k + 1]));
+    w += nd;
+    start += 2 * nd;
+    if (w < need && start == kMtN - 1) {
+      carry = mt_temper(mt[kMtN - 1]);
+      have_carry = true;
+      start = kMtN;
+    }
+    pos = start;
+    __syncthreads();
+  }
+  for (int k = tid; k < kMtN; k += kRngBlock) state->mt[k] = mt[k];
+  if (tid == 0) state->pos = pos;
+}
+
+}  // namespace sc

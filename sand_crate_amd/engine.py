@@ -274,6 +274,27 @@ class Engine:
         N.check(self._lib.sc_owned_count(self._ctx, C.byref(n)))
         return n.value
 
+    # -- NumPy's global MT19937 stream on the device
+    def rng_set_state(self, key, pos: int) -> None:
+        """Hand the stream of `np.random.get_state()` (624-word key, position) to the device."""
+        k = np.ascontiguousarray(key, dtype=np.uint32).reshape(624)
+        N.check(self._lib.sc_rng_set_state(self._ctx, k.ctypes.data_as(C.POINTER(C.c_uint32)), int(pos)))
+
+    def rng_get_state(self):
+        """-> (key, position) of the device stream; synchronises."""
+        k = np.zeros(624, dtype=np.uint32)
+        pos = C.c_int32(0)
+        N.check(self._lib.sc_rng_get_state(self._ctx, k.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos)))
+        return k, pos.value
+
+    def emit_particles(self, sources, dt: float, max_particles: int) -> None:
+        """particle_source.py:17-24 for `sources` (objects with radius, position, velocity, flow, noise) on the device."""
+        arr = (N.Source * max(len(sources), 1))()
+        for k, s in enumerate(sources):
+            arr[k] = N.Source(float(s.radius), float(s.position[0]), float(s.position[1]), float(s.velocity[0]),
+                              float(s.velocity[1]), float(s.noise), int(s.flow))
+        N.check(self._lib.sc_emit_particles(self._ctx, arr, len(sources), float(dt), int(max_particles)))
+
     # -- timing
     def enable_timing(self, on: bool = True) -> None:
         N.check(self._lib.sc_enable_timing(self._ctx, 1 if on else 0))
