@@ -142,6 +142,27 @@ def fp64_issue(particles_per_gpu: int, kernels: dict):
     return out
 
 
+def drop_in_ticks(ticks: int = 300):
+    """The path the reference's viewer calls -- `Crate.physics_tick()` once per frame on config/wave_machine.yaml as
+    shipped (particle source active, collider noise from NumPy's MT19937 stream) -- timed tick by tick with the
+    stream generated on the device (noise="host", no per-tick synchronisation) and with the host drawing it
+    (noise="host-sync": count readback + np.random + upload every tick)."""
+    import sand_crate_amd as sc
+    out = {"workload": f"config/wave_machine.yaml from tick 0, {ticks} x physics_tick()"}
+    for mode in ("host", "host-sync"):
+        crate = sc.Crate(sc.load_config(ROOT / "config" / "wave_machine.yaml").world_config, noise=mode)
+        for _ in range(20):
+            crate.physics_tick()
+        crate.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(ticks):
+            crate.physics_tick()
+        crate.synchronize()
+        dt = time.perf_counter() - t0
+        out[mode] = {"ms_per_tick": round(1000.0 * dt / ticks, 4), "particles_at_end": int(crate.particle_count)}
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -338,6 +359,8 @@ def main() -> None:
         line["kernels"] = kernels
         if device_flags:
             line["device_flags"] = sorted(set(device_flags))
+        if world == 1:
+            line["drop_in_physics_tick"] = drop_in_ticks()
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         print(json.dumps(line))

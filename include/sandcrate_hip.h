@@ -250,6 +250,25 @@ int sc_halo_exchange(sc_ctx* ctx, const double* send_left, int64_t send_left_rec
                      int64_t recv_left_records, int32_t left_rank, const double* send_right, int64_t send_right_records,
                      double* recv_right, int64_t recv_right_records, int32_t right_rank);
 
+/* Force monitor: the reference's HUD shows the mean |dv| of each force phase (force_monitor.py:13-37 around
+ * crate.py:110-123).  While enabled, the force kernel also sums |dv| per particle and phase -- tension, gravity,
+ * pressure, viscosity, wall_bounce, continuous_collision, in this order -- without changing any result (ticks are
+ * then never fused with their successor's wall pass).  sc_get_force_monitor returns the six sums and the number
+ * of particles summed since the last call and clears them; it synchronises. */
+int sc_enable_force_monitor(sc_ctx* ctx, int on);
+int sc_get_force_monitor(sc_ctx* ctx, double* sums_6, int64_t* particles);
+
+/* Checkpoint.  sc_checkpoint_begin copies the stored state (positions, velocities, ids, counters, the MT19937
+ * stream if the device holds it) device-to-device on the context's stream and sends the copy to pinned host memory
+ * on a side stream; it returns at once and later ticks overlap the transfer.  sc_checkpoint_finish waits for that
+ * transfer only and delivers the particles in particle-index order with the tick they belong to, the id the next
+ * emitted particle gets, and the generator state (rng_position = -1: the host holds the stream).  One checkpoint
+ * at a time.  sc_restore_counters, after sc_upload_state_ids on a fresh context, puts tick and next id back. */
+int sc_checkpoint_begin(sc_ctx* ctx);
+int sc_checkpoint_finish(sc_ctx* ctx, double* xy, double* vxy, int64_t* ids, int64_t room, int64_t* n_out, int64_t* tick,
+                         int64_t* next_id, uint32_t* rng_key_624, int32_t* rng_position);
+int sc_restore_counters(sc_ctx* ctx, int64_t tick, int64_t next_id);
+
 /* NumPy's legacy global generator on the device (the reference draws particle sources and collider noise from
  * `np.random`, seeded in Crate.__init__, crate.py:22).  sc_rng_set_state hands the stream to the context -- the
  * 624-word key and the position of `np.random.get_state()` -- and from then on

@@ -102,6 +102,12 @@ SIGNATURES = {
     "sc_comm_destroy": (C.c_int, [_P]),
     "sc_halo_exchange": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P, C.c_int64, _P, C.c_int64, C.c_int32]),
     "sc_owned_count": (C.c_int, [_P, _I64]),
+    "sc_enable_force_monitor": (C.c_int, [_P, C.c_int]),
+    "sc_get_force_monitor": (C.c_int, [_P, _D, _I64]),
+    "sc_checkpoint_begin": (C.c_int, [_P]),
+    "sc_checkpoint_finish": (C.c_int, [_P, _D, _D, _I64, C.c_int64, _I64, _I64, _I64, C.POINTER(C.c_uint32),
+                                      C.POINTER(C.c_int32)]),
+    "sc_restore_counters": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "sc_rng_set_state": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int32]),
     "sc_rng_get_state": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
     "sc_emit_particles": (C.c_int, [_P, C.POINTER(Source), C.c_int32, C.c_double, C.c_int64]),

@@ -34,6 +34,8 @@ There is no CPU implementation behind this class: without libsandcrate_hip.so an
 """
 from __future__ import annotations
 
+import copy
+import json
 import time
 
 import numpy as np
@@ -47,6 +49,7 @@ from .rigid_body import build_rigid_bodies
 from .utils.geometry_utils import pad_segments
 
 _NOISE_MODES = {"none": N.NOISE_NONE, "host": N.NOISE_HOST, "host-sync": N.NOISE_HOST, "counter": N.NOISE_COUNTER}
+FORCE_PHASES = ("tension", "gravity", "pressure", "viscosity", "wall_bounce", "continuous_collision")  # crate.py:110-123
 _TICK_COEFFICIENTS = ("dt", "particle_radius", "wall_collision_decay", "pressure_amplifier", "ignored_pressure",
                       "collider_noise_level", "viscosity", "surface_smoothing", "target_pressure")
 
@@ -102,6 +105,9 @@ class Crate:
         self._pad_cache = {}
         self._hud_kernels = False
         self._kernel_seconds = {}
+        self._hud_forces = False
+        self._force_ema = {}
+        self._pending_checkpoint = None
         self.last_stats = None
 
     # ------------------------------------------------------------------ reference accessors
@@ -237,6 +243,11 @@ class Crate:
                 if launches:
                     self._kernel_seconds[name] = 0.9 * self._kernel_seconds.get(name, 0.0) + 0.1 * ms / 1000.0
             eng.reset_timing()
+        if self._hud_forces:  # force_monitor.py:27-33: EMA (0.80) of the mean |dv| of each force phase
+            sums, count = eng.force_monitor()
+            if count:
+                for name, total in zip(FORCE_PHASES, sums):
+                    self._force_ema[name] = 0.8 * self._force_ema.get(name, 0.0) + 0.2 * total / count
         dt_wall = time.perf_counter() - t0
         self._tick_seconds = 0.9 * self._tick_seconds + 0.1 * dt_wall
         self.set_debug_prints()
@@ -250,6 +261,98 @@ class Crate:
         self._kernel_seconds = {}
         self._engine.reset_timing()
         self._engine.enable_timing(self._hud_kernels)
+
+    def show_forces(self, on: bool = True) -> None:
+        """The `Forces` block of the reference's HUD (force_monitor.py:35-37, printed at crate.py:135): mean |dv| of
+        tension, gravity, pressure, viscosity, wall_bounce and continuous_collision, EMA 0.80, times 1000.  The force
+        kernel sums |dv| per phase on the side (results unchanged); costs one synchronisation per tick."""
+        self._hud_forces = bool(on)
+        self._force_ema = {}
+        self._engine.enable_force_monitor(self._hud_forces)
+
+    # ------------------------------------------------------------------ checkpoint (the reference's commented zarr dump,
+    # playback.py:109-118, grown into something a run can resume from)
+    def begin_checkpoint(self) -> None:
+        """Capture the whole simulation state as of now.  Returns at once: the particle state is copied on the device
+        and travels to pinned host memory on a side stream while later ticks run; `finish_checkpoint` collects it."""
+        if self._pending_checkpoint is not None:
+            raise RuntimeError("a checkpoint is already under way")
+        self._engine.checkpoint_begin()
+        bodies = []
+        for body in self.rigid_bodies:
+            bodies.append({"segments": body.segments.tolist(), "position": [float(x) for x in body.position],
+                           "center_velocity": np.asarray(body.center_velocity, dtype=np.float64).tolist(),
+                           "angular_clockwise_velocity": float(body.angular_clockwise_velocity),
+                           "time_from_start": float(getattr(body, "time_from_start", 0.0))})
+        coefficients = {}
+        for name in self.editable_coefficients():
+            value = getattr(self, name)
+            coefficients[name] = value.tolist() if isinstance(value, np.ndarray) else value
+        host_rng = None
+        if self._noise != "host":  # the host owns the global stream (the device's copy travels with the particles)
+            _, key, pos, has_gauss, cached = np.random.get_state()
+            host_rng = {"key": key.tolist(), "pos": int(pos), "has_gauss": int(has_gauss), "cached_gaussian": float(cached)}
+        wc = self.world_config
+        self._pending_checkpoint = {
+            "format": 1, "tick": int(self.tick), "noise": self._noise, "noise_seed": int(self._noise_seed),
+            "world_config": {"rigid_bodies": copy.deepcopy(wc.rigid_bodies), "particle_sources": copy.deepcopy(wc.particle_sources),
+                             "coefficients": coefficients},
+            "bodies": bodies, "host_rng": host_rng, "pressure": self._cache[2] if self._cache is not None else None}
+
+    def finish_checkpoint(self, path) -> None:
+        """Wait for the transfer `begin_checkpoint` started (not for later ticks) and write the .npz file."""
+        if self._pending_checkpoint is None:
+            raise RuntimeError("begin_checkpoint first")
+        meta, self._pending_checkpoint = self._pending_checkpoint, None
+        snap = self._engine.checkpoint_finish()
+        pressure = meta.pop("pressure")
+        meta["next_id"] = int(snap["next_id"])
+        meta["engine_tick"] = int(snap["tick"])
+        arrays = {"particles": snap["particles"], "velocities": snap["velocities"], "ids": snap["ids"]}
+        if pressure is not None and len(pressure) == len(snap["ids"]):
+            arrays["pressure"] = pressure
+        if snap["rng"] is not None:
+            arrays["rng_key"] = snap["rng"][0]
+            meta["rng_pos"] = int(snap["rng"][1])
+        np.savez(path, meta=np.array(json.dumps(meta)), **arrays)
+
+    def save_checkpoint(self, path) -> None:
+        self.begin_checkpoint()
+        self.finish_checkpoint(path)
+
+    @classmethod
+    def from_checkpoint(cls, path, *, device: int = 0, capacity: int | None = None) -> "Crate":
+        """A crate that continues the run `save_checkpoint` captured: same particles (and ids), velocities, tick,
+        wall positions and motor clocks, coefficients as edited, and the random stream where it stood."""
+        with np.load(path, allow_pickle=False) as z:
+            meta = json.loads(str(z["meta"]))
+            arrays = {k: z[k] for k in z.files if k != "meta"}
+        wc = meta["world_config"]
+        crate = cls(WorldConfig(rigid_bodies=wc["rigid_bodies"], particle_sources=wc["particle_sources"],
+                                coefficients=wc["coefficients"]),
+                    device=device, noise=meta["noise"], noise_seed=meta["noise_seed"], capacity=capacity)
+        for body, saved in zip(crate.rigid_bodies, meta["bodies"]):
+            body.segments = np.array(saved["segments"], dtype=np.float64)
+            body.position = list(saved["position"])
+            body.center_velocity = np.array(saved["center_velocity"], dtype=np.float64)
+            body.angular_clockwise_velocity = saved["angular_clockwise_velocity"]
+            if hasattr(body, "time_from_start"):
+                body.time_from_start = saved["time_from_start"]
+        n = len(arrays["ids"])
+        if n > crate._engine.capacity:
+            crate._grow(n)
+        eng = crate._engine
+        eng.upload_with_ids(arrays["particles"], arrays["velocities"], arrays["ids"])
+        eng.restore_counters(meta["engine_tick"], meta["next_id"])
+        crate.tick = meta["tick"]
+        crate._count, crate._count_known = n, True
+        crate._cache = (arrays["particles"], arrays["velocities"], arrays.get("pressure", np.zeros(n)))
+        if "rng_key" in arrays:
+            eng.rng_set_state(arrays["rng_key"], meta["rng_pos"])
+        elif meta["host_rng"] is not None:
+            h = meta["host_rng"]
+            np.random.set_state(("MT19937", np.array(h["key"], dtype=np.uint32), h["pos"], h["has_gauss"], h["cached_gaussian"]))
+        return crate
 
     def run(self, n_ticks: int) -> None:
         """`n_ticks` ticks back to back without touching the host state in between (no sources
@@ -357,6 +460,9 @@ class Crate:
                 timing[name] = f"{1000 * seconds:.3f} ms ({100 * seconds / frame:.0f}%)"
         self.debug_prints += yaml.dump({"Timing": timing,
                                         "FPS": f"{int(1 / frame) if frame > 0 else 0} ({1000 * frame:.0f} ms)"})
+        if self._hud_forces:  # force_monitor.py:35-37, in the place crate.py:135 gives it
+            rounded = {name: float(f"{1000 * value:.1f}") for name, value in self._force_ema.items()}
+            self.debug_prints += f"\n\n{yaml.dump({'Forces': rounded})}"
         self.debug_prints += f"\n\n{self.get_coefficient_debug()}"
 
     def get_coefficient_debug(self) -> str:

@@ -89,7 +89,22 @@ struct sc_ctx {
   double *haloL = nullptr, *haloR = nullptr;  // send buffers of the last sc_halo_pack (caller-owned device memory)
   int haloCap = 0;
   int64_t halo_ring_from = 0;  // first tick whose halo counts in the progress block belong to the current state
+  int64_t live_hint_from = 0;  // the live count the device publishes is usable once a tick >= this one has finished
   RngState* rng = nullptr;     // NumPy's MT19937 stream on the device (sc_rng_set_state), or null
+  double* monitor = nullptr;   // force monitor: sum of |dv| per phase and the particle count (sc_enable_force_monitor)
+  bool monitor_on = false;
+  // checkpoint (sc_checkpoint_begin / _finish): device-side snapshot, pinned host copy, side stream
+  double* snap_d[4] = {};
+  int* snap_id_d = nullptr;
+  RngState* snap_rng_d = nullptr;
+  double* snap_h[4] = {};
+  int* snap_id_h = nullptr;
+  int* snap_counters_h = nullptr;  // C_COUNT counters + [C_COUNT] = RngState follows in snap_rng_h
+  RngState* snap_rng_h = nullptr;
+  int64_t snapAlloc = 0, snap_n_bound = 0, snap_tick = -1;
+  bool snap_has_rng = false, snap_pending = false;
+  hipStream_t side_stream = nullptr;
+  hipEvent_t snap_ready = nullptr, snap_done = nullptr;
   int* colHist = nullptr;      // sc_column_histogram
   int64_t colHistAlloc = 0;
   int* rankAcc = nullptr;  // per bucket slot: rank inside a big bucket (k_rank_big adds, k_reorder takes and clears)
@@ -404,6 +419,7 @@ int put_particles(sc_ctx* c, const double* xy, const double* vxy, int64_t n, boo
   }
   c->upper = base + n;
   c->next_id += n;
+  c->live_hint_from = c->tick;  // counts published by earlier ticks do not include these particles
   hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, c->stream, c->counters, (int)n, reset ? 1 : 0, (int)c->next_id);
   HIPCHK(hipGetLastError());
   return SC_OK;
@@ -436,20 +452,22 @@ void launch_pass_a(sc_ctx* c, int kernel_id) {
     launch_pass_a_cap<NOISE, ENUM, DENS, kTileCapA>(c);
 }
 
-template <int NOISE, bool FUSED>
+template <int NOISE, bool FUSED, bool MON = false>
 void launch_pass_b(sc_ctx* c, const WallInputs& wn) {
   Bracket br(c, K_FORCE);
   const int cur = (int)(c->tick & 1), nxt = cur ^ 1;
-  hipLaunchKernelGGL((k_pass_b<NOISE, FUSED>), dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters, c->x[1],
+  hipLaunchKernelGGL((k_pass_b<NOISE, FUSED, MON>), dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters, c->x[1],
                      c->y[1], c->vx[1], c->vy[1], c->id[1], c->wslotT, c->cellT, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta,
                      c->offById, c->P, c->sx, c->sy, c->wrec[cur], c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0],
                      c->tileBounds, c->bigHintDev, wn, c->cellS, c->wslotS, c->cellCount, c->wrec[nxt], c->haloL, c->haloR,
-                     c->haloCap);
+                     c->haloCap, c->monitor);
 }
 
 template <int NOISE>
 void launch_pass_b_any(sc_ctx* c, bool fused, const WallInputs& wn) {
-  if (fused)
+  if (c->monitor_on)
+    launch_pass_b<NOISE, false, true>(c, wn);
+  else if (fused)
     launch_pass_b<NOISE, true>(c, wn);
   else
     launch_pass_b<NOISE, false>(c, wn);
@@ -535,7 +553,8 @@ int sc_destroy(sc_ctx* c) {
   }
   void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->rankAcc, c->wrec[0], c->wrec[1],
                   c->nbr, c->nbr16, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
-                  c->stage_xy, c->stage_vxy, c->stage_ids, c->owned_out, c->colHist, c->rng};
+                  c->stage_xy, c->stage_vxy, c->stage_ids, c->owned_out, c->colHist, c->rng, c->monitor,
+                  c->snap_d[0], c->snap_d[1], c->snap_d[2], c->snap_d[3], c->snap_id_d, c->snap_rng_d};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& v : {c->ev_used, c->ev_free})
@@ -543,6 +562,12 @@ int sc_destroy(sc_ctx* c) {
       (void)hipEventDestroy(e.a);
       (void)hipEventDestroy(e.b);
     }
+  for (void* p : {(void*)c->snap_h[0], (void*)c->snap_h[1], (void*)c->snap_h[2], (void*)c->snap_h[3], (void*)c->snap_id_h,
+                  (void*)c->snap_counters_h, (void*)c->snap_rng_h})
+    if (p) (void)hipHostFree(p);
+  if (c->snap_ready) (void)hipEventDestroy(c->snap_ready);
+  if (c->snap_done) (void)hipEventDestroy(c->snap_done);
+  if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
   if (c->bigHintHost) (void)hipHostFree(c->bigHintHost);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -787,7 +812,7 @@ int sc_step_finish(sc_ctx* c) {
   WallInputs wn;
   std::memset(&wn, 0, sizeof wn);
   const bool slab_ready = !c->slab || c->haloL || !(c->has_left || c->has_right);
-  const bool fused = c->have_next && slab_ready && !c->custom_grid;
+  const bool fused = c->have_next && slab_ready && !c->custom_grid && !c->monitor_on;  // the monitor runs with the plain kernel
   if (fused) {
     World next;
     int rc = build_world(c, next, c->next_params, c->next_nseg, c->next_seg, nullptr, c->next_nbody, c->next_body,
@@ -1342,6 +1367,148 @@ int sc_owned_count(sc_ctx* c, int64_t* n) {
   return SC_OK;
 }
 
+// ---- force monitor ------------------------------------------------------------------------------
+
+int sc_enable_force_monitor(sc_ctx* c, int on) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  if (c->in_step) return fail(SC_ERR_STATE, "the force monitor cannot change inside a tick");
+  if (c->prebinned) return fail(SC_ERR_STATE, "the force monitor cannot change after sc_set_next_inputs promised the next tick");
+  HIPCHK(hipSetDevice(c->device));
+  if (on && !c->monitor) HIPCHK(dalloc(&c->monitor, (size_t)kMonPhases + 1));
+  if (on) HIPCHK(hipMemsetAsync(c->monitor, 0, (kMonPhases + 1) * sizeof(double), c->stream));
+  c->monitor_on = on != 0;
+  return SC_OK;
+}
+
+int sc_get_force_monitor(sc_ctx* c, double* sums, int64_t* particles) {
+  if (!c || !sums || !particles) return fail(SC_ERR_ARG, "null argument");
+  if (!c->monitor_on) return fail(SC_ERR_STATE, "sc_enable_force_monitor first");
+  double h[kMonPhases + 1];
+  HIPCHK(hipMemcpyAsync(h, c->monitor, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemsetAsync(c->monitor, 0, sizeof h, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < kMonPhases; ++k) sums[k] = h[k];
+  *particles = (int64_t)h[kMonPhases];
+  return SC_OK;
+}
+
+// ---- checkpoint ---------------------------------------------------------------------------------
+// The stored state is copied device-to-device on the context's stream (a few microseconds), the copy travels to
+// pinned host memory on a side stream, and the ticks that follow run meanwhile; sc_checkpoint_finish waits for the
+// side stream only.
+
+int sc_checkpoint_begin(sc_ctx* c) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  if (c->in_step) return fail(SC_ERR_STATE, "sc_checkpoint_begin inside a tick");
+  if (c->snap_pending) return fail(SC_ERR_STATE, "a checkpoint is already under way: sc_checkpoint_finish first");
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->side_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->snap_ready, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->snap_done, hipEventDisableTiming));
+    HIPCHK(hipHostMalloc((void**)&c->snap_counters_h, C_COUNT * sizeof(int), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&c->snap_rng_h, sizeof(RngState), hipHostMallocDefault));
+    HIPCHK(dalloc(&c->snap_rng_d, 1));
+  }
+  const int64_t n = launch_bound(c);  // a host-side bound of the stored count; the exact count travels with the copy
+  if (n > c->snapAlloc) {
+    HIPCHK(hipStreamSynchronize(c->side_stream));
+    for (int k = 0; k < 4; ++k) {
+      if (c->snap_d[k]) (void)hipFree(c->snap_d[k]);
+      if (c->snap_h[k]) (void)hipHostFree(c->snap_h[k]);
+      c->snap_d[k] = nullptr;
+      c->snap_h[k] = nullptr;
+    }
+    if (c->snap_id_d) (void)hipFree(c->snap_id_d);
+    if (c->snap_id_h) (void)hipHostFree(c->snap_id_h);
+    c->snap_id_d = nullptr;
+    c->snap_id_h = nullptr;
+    const int64_t m = std::min<int64_t>(c->cap, n + n / 2 + 1024);
+    for (int k = 0; k < 4; ++k) {
+      HIPCHK(dalloc(&c->snap_d[k], (size_t)m));
+      HIPCHK(hipHostMalloc((void**)&c->snap_h[k], std::max<size_t>(m, 1) * sizeof(double), hipHostMallocDefault));
+    }
+    HIPCHK(dalloc(&c->snap_id_d, (size_t)m));
+    HIPCHK(hipHostMalloc((void**)&c->snap_id_h, std::max<size_t>(m, 1) * sizeof(int), hipHostMallocDefault));
+    c->snapAlloc = m;
+  }
+  const double* src[4] = {c->x[0], c->y[0], c->vx[0], c->vy[0]};
+  // on the context's stream: after the last tick, before the next one changes the storage arrays
+  for (int k = 0; k < 4 && n > 0; ++k)
+    HIPCHK(hipMemcpyAsync(c->snap_d[k], src[k], n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  if (n > 0) HIPCHK(hipMemcpyAsync(c->snap_id_d, c->id[0], n * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+  c->snap_has_rng = c->rng != nullptr;
+  if (c->rng) HIPCHK(hipMemcpyAsync(c->snap_rng_d, c->rng, sizeof(RngState), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->snap_counters_h, c->counters, C_COUNT * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipEventRecord(c->snap_ready, c->stream));
+  // on the side stream: the snapshot goes to pinned host memory while the context's stream runs on
+  HIPCHK(hipStreamWaitEvent(c->side_stream, c->snap_ready, 0));
+  for (int k = 0; k < 4 && n > 0; ++k)
+    HIPCHK(hipMemcpyAsync(c->snap_h[k], c->snap_d[k], n * sizeof(double), hipMemcpyDeviceToHost, c->side_stream));
+  if (n > 0) HIPCHK(hipMemcpyAsync(c->snap_id_h, c->snap_id_d, n * sizeof(int), hipMemcpyDeviceToHost, c->side_stream));
+  if (c->rng) HIPCHK(hipMemcpyAsync(c->snap_rng_h, c->snap_rng_d, sizeof(RngState), hipMemcpyDeviceToHost, c->side_stream));
+  HIPCHK(hipEventRecord(c->snap_done, c->side_stream));
+  c->snap_n_bound = n;
+  c->snap_tick = c->tick;
+  c->snap_pending = true;
+  return SC_OK;
+}
+
+int sc_checkpoint_finish(sc_ctx* c, double* xy, double* vxy, int64_t* ids, int64_t room, int64_t* n_out, int64_t* tick,
+                         int64_t* next_id, uint32_t* rng_key, int32_t* rng_pos) {
+  if (!c || !n_out) return fail(SC_ERR_ARG, "null argument");
+  if (!c->snap_pending) return fail(SC_ERR_STATE, "sc_checkpoint_begin first");
+  HIPCHK(hipEventSynchronize(c->snap_ready));  // the counters' copy rode on the context's stream up to here
+  HIPCHK(hipEventSynchronize(c->snap_done));
+  c->snap_pending = false;
+  const int64_t stored = std::min<int64_t>(c->snap_counters_h[C_NS], c->snap_n_bound);
+  std::vector<int> order;
+  order.reserve(stored);
+  for (int64_t k = 0; k < stored; ++k)
+    if (std::isfinite(c->snap_h[0][k])) order.push_back((int)k);  // slab mode leaves dead ghost copies (x = +inf) behind
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return c->snap_id_h[a] < c->snap_id_h[b]; });
+  const int64_t n = (int64_t)order.size();
+  *n_out = n;
+  if (tick) *tick = c->snap_tick;
+  if (next_id) *next_id = c->snap_counters_h[C_NEXT_ID];
+  if (rng_pos) *rng_pos = c->snap_has_rng ? c->snap_rng_h->pos : -1;
+  if (rng_key && c->snap_has_rng) std::memcpy(rng_key, c->snap_rng_h->mt, sizeof c->snap_rng_h->mt);
+  if (n > room) return fail(SC_ERR_CAPACITY, "host arrays hold %lld, the checkpoint has %lld particles", (long long)room, (long long)n);
+  for (int64_t k = 0; k < n; ++k) {
+    const int s = order[k];
+    if (xy) {
+      xy[2 * k] = c->snap_h[0][s];
+      xy[2 * k + 1] = c->snap_h[1][s];
+    }
+    if (vxy) {
+      vxy[2 * k] = c->snap_h[2][s];
+      vxy[2 * k + 1] = c->snap_h[3][s];
+    }
+    if (ids) ids[k] = c->snap_id_h[s];
+  }
+  return SC_OK;
+}
+
+int sc_restore_counters(sc_ctx* c, int64_t tick, int64_t next_id) {
+  if (!c || tick < 0 || next_id < 0 || next_id > std::numeric_limits<int>::max()) return fail(SC_ERR_ARG, "bad tick / next id");
+  if (c->in_step) return fail(SC_ERR_STATE, "sc_restore_counters inside a tick");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->prebinned) {  // a promised tick is abandoned: forget its bucket counts
+    HIPCHK(hipMemsetAsync(c->cellCount, 0, c->cellAlloc * sizeof(int), c->stream));
+    c->prebinned = false;
+  }
+  c->tick = tick;
+  c->halo_ring_from = tick;
+  c->live_hint_from = tick;
+  c->bigHintHost[1] = (int)tick;  // "ticks finished": nothing of the new numbering is queued
+  c->next_id = std::max<int64_t>(c->next_id, next_id);
+  const int nid = (int)c->next_id;
+  HIPCHK(hipMemcpyAsync(c->counters + C_NEXT_ID, &nid, sizeof nid, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return SC_OK;
+}
+
 // ---- NumPy's global MT19937 stream on the device (sc_rng.h) -------------------------------------
 
 int sc_rng_set_state(sc_ctx* c, const uint32_t* key, int32_t pos) {
@@ -1400,7 +1567,8 @@ int sc_emit_particles(sc_ctx* c, const sc_source* sources, int32_t n_sources, do
   // recent tick published (progress block) keeps the bound from drifting away without any synchronisation
   const int64_t done = *(volatile int*)(c->bigHintHost + 1), live = *(volatile int*)(c->bigHintHost + 2);
   int64_t upper = c->upper + most;
-  if (done > 0 && c->tick >= done && c->tick - done <= 8) upper = std::min(upper, live + (c->tick - done + 1) * most);
+  if (done > c->live_hint_from && c->tick >= done && c->tick - done <= 8)
+    upper = std::min(upper, live + (c->tick - done + 1) * most);
   upper = std::min<int64_t>(upper, std::max<int64_t>(max_particles, c->upper));
   if (upper > c->cap) {
     int h[C_COUNT];

@@ -502,7 +502,8 @@ __global__ void __launch_bounds__(kTileW)
 // neighbors' start-of-tick velocities are only summed (crate.py:175, :319-323): they are staged into the
 // (x, y) array once the pair loop is done with it.
 struct PairSums {
-  double tx, ty;  // the velocity change of apply_tension + the particle part of apply_pressure, dt included
+  double tx, ty;    // the velocity change of apply_tension + the particle part of apply_pressure, dt included
+  double mtx, mty;  // force monitor only: the share of apply_tension in it
 };
 
 // Phase 3a of pass B for one particle: the pair loop.  LDS: where the tile is (compile time, see the
@@ -512,7 +513,7 @@ struct PairSums {
 // Neither reads a velocity, and gravity in between is a constant, so the two sums are taken together:
 //   dv = sum_j w_j n_ij,   w_j = (dt ss) (ds . n_ij) + (P_i + P_j) dt (1 + pamp) - 2 tp dt,   n_ij = r rinv
 // (one multiply-add chain per pair instead of two accumulations; rounding differs at 1e-16).
-template <int NOISE, bool LDS>
+template <int NOISE, bool LDS, bool MON>
 __device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl, const XY* txy, const XY* tss,
                                                  const double* tP, const int self, const int Cn, const int idi,
                                                  const int (&js)[kMaxNbr], const double* __restrict__ x,
@@ -542,7 +543,7 @@ __device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl,
   const int off = (NOISE == SC_NOISE_HOST) ? offById[idi] : 0;
   const uint64_t zbase = noise_base(w.noise_key, idi);
   const double k_ss = w.dt * w.ss, k_pp = w.dt * (1 + w.pamp), k_0 = -2 * w.tp * w.dt;
-  double tx = 0, ty = 0;
+  double tx = 0, ty = 0, mtx = 0, mty = 0;
 #pragma unroll
   for (int s = 0; s < kMaxNbr; ++s) {
     if (s < Cn) {
@@ -556,19 +557,30 @@ __device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl,
       const double wr = fma(dot, k_ss, fma(Pi + oP, k_pp, k_0)) * rinv;
       tx += wr * rx;
       ty += wr * ry;
+      if constexpr (MON) {  // the tension share on its own, next to -- not instead of -- the sums above
+        const double wt = fma(dot, k_ss, fma(Pi + oP, w.dt, k_0)) * rinv;
+        mtx += wt * rx;
+        mty += wt * ry;
+      }
     }
   }
-  return PairSums{tx, ty};
+  return PairSums{tx, ty, mtx, mty};
 }
 
 // Phases 3b-4 of pass B for one particle: the sum of the neighbors' start-of-tick velocities (from `tv`,
 // the (vx, vy) of the tile, or from global memory) and the per-particle epilogue.
-template <bool LDS>
+// MON: the force monitor of the reference's HUD (force_monitor.py:13-37 wraps the six force phases of
+// crate.py:110-123 and averages |dv| of each) -- `mon` receives this particle's |dv| per phase, in the order
+// tension, gravity, pressure, viscosity, wall_bounce, continuous_collision.
+constexpr int kMonPhases = 6;
+template <bool LDS, bool MON>
 __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, const XY* tv, const int C, const int Cn,
                                               const int ws, const int (&js)[kMaxNbr], const double* __restrict__ vx,
                                               const double* __restrict__ vy, const double* __restrict__ wrec,
                                               const PairSums ps, const double xi, const double yi, const double Pi,
-                                              double vxi, double vyi, double& xn, double& yn, double& vxn, double& vyn) {
+                                              double vxi, double vyi, double& xn, double& yn, double& vxn, double& vyn,
+                                              double (&mon)[kMonPhases]) {
+  auto norm2 = [](double a, double b) { return sqrt(a * a + b * b); };
   double ux = 0, uy = 0;
 #pragma unroll
   for (int s = 0; s < kMaxNbr; ++s) {
@@ -593,16 +605,27 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
   vyi += ps.ty;
   vxi += w.dt * w.gx;  // crate.py:310
   vyi += w.dt * w.gy;
+  double wallx = 0, wally = 0;
   if (ws >= 0) {
     const double* rec = wrec + 5 * (size_t)ws;
     Ux = rec[0]; Uy = rec[1]; Cx = rec[2]; Cy = rec[3]; V = rec[4];
     const double dpa = w.dt * w.pamp * Pi;  // wall colliders carry pressure 0 and are not normalised (crate.py:286-306)
-    vxi += dpa * Ux;
-    vyi += dpa * Uy;
+    wallx = dpa * Ux;
+    wally = dpa * Uy;
+    vxi += wallx;
+    vyi += wally;
   }
   const double dv = w.dt * w.visc;  // crate.py:319-323: sum_j (v0_j - v_i), v_i the current velocity
-  vxi += dv * (ux - C * vxi);
-  vyi += dv * (uy - C * vyi);
+  const double visx = dv * (ux - C * vxi), visy = dv * (uy - C * vyi);
+  vxi += visx;
+  vyi += visy;
+  if constexpr (MON) {
+    mon[0] = norm2(ps.mtx, ps.mty);
+    mon[1] = norm2(w.dt * w.gx, w.dt * w.gy);
+    mon[2] = norm2(ps.tx - ps.mtx + wallx, ps.ty - ps.mty + wally);
+    mon[3] = norm2(visx, visy);
+    mon[4] = mon[5] = 0.0;
+  }
   }
   if (ws >= 0) {  // crate.py:245-259
     double nx = Ux / V, ny = Uy / V;
@@ -613,10 +636,12 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
     const double qq = (vxi - cvx) * nx + (vyi - cvy) * ny;
     if (qq < 0) {
       const double cx = -1 * qq * nx, cy = -1 * qq * ny;
+      const double bx0 = vxi, by0 = vyi;
       vxi += cx;
       vyi += cy;
       vxi += cx * w.decay;
       vyi += cy * w.decay;
+      if constexpr (MON) mon[4] = norm2(vxi - bx0, vyi - by0);
     }
   }
   // continuous collision: movement p -> p + v*dt against the 2S padded segments
@@ -643,6 +668,7 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
         if (f < fac) fac = f;  // crate.py:198-199
       }
     }
+    if constexpr (MON) mon[5] = norm2(vxi * fac - vxi, vyi * fac - vyi);
     vxi *= fac;  // crate.py:200
     vyi *= fac;
   }
@@ -656,7 +682,7 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
 // index, bucket count -- sc_kernels.h: wall_and_cell) on the freshly integrated position, with the
 // next tick's walls `wn` (sc_set_next_inputs).  That tick then starts at the bucket scan: one launch
 // and one read+write of the positions less per tick.
-template <int NOISE, bool FUSED>
+template <int NOISE, bool FUSED, bool MON = false>
 __global__ void __launch_bounds__(kTileW)
     k_pass_b(World w, int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
              const double* __restrict__ vx, const double* __restrict__ vy, const int* __restrict__ id,
@@ -669,7 +695,8 @@ __global__ void __launch_bounds__(kTileW)
              const int* __restrict__ tileBounds, volatile int* __restrict__ progress,
              WallInputs wn, int* __restrict__ cellS, int* __restrict__ wslotS, int* __restrict__ cellCount,
              double* __restrict__ wrec_next, double* __restrict__ haloL,
-             double* __restrict__ haloR, int haloCap) {
+             double* __restrict__ haloR, int haloCap, double* __restrict__ monitor) {
+  static_assert(!(MON && FUSED), "the force monitor runs with the plain force kernel");
   __shared__ XY txy[kTileCapB];   // (x, y) of the tile; (vx, vy) once the pair loop is done
   __shared__ XY tss[kTileCapB];   // (sx, sy)
   __shared__ double tP[kTileCapB];
@@ -764,14 +791,15 @@ __global__ void __launch_bounds__(kTileW)
 
   SC_STAMP(1, 2);
   // 3-4. pair math and epilogue; ghosts and lanes without a particle skip it
+  double mon[kMonPhases] = {0, 0, 0, 0, 0, 0};
   double xn = __builtin_huge_val(), yn = 0.0, vxn = 0.0, vyn = 0.0;  // a ghost's copy: +inf makes the next
   int idn = -1;                                                        // removal test (crate.py:152) drop it
   const bool active = live && !ghost;
   const int self = i - tl.a0;
   if (in_lds) {
-    PairSums ps{0, 0};
+    PairSums ps{0, 0, 0, 0};
     double xi = 0, yi = 0, Pi = 0;
-    if (active) ps = pass_b_pairs<NOISE, true>(w, tl, txy, tss, tP, self, Cn, idi, js, x, y, eta, offById, P, sx, sy, xi, yi, Pi);
+    if (active) ps = pass_b_pairs<NOISE, true, MON>(w, tl, txy, tss, tP, self, Cn, idi, js, x, y, eta, offById, P, sx, sy, xi, yi, Pi);
     SC_STAMP(1, 3);
     __syncthreads();  // everybody is done with (x, y): the array now takes the velocities
 #pragma unroll
@@ -783,15 +811,24 @@ __global__ void __launch_bounds__(kTileW)
     SC_STAMP(1, 4);
     if (active) {
       idn = idi;
-      pass_b_finish<true>(w, tl, txy, C, Cn, ws, js, vx, vy, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn);
+      pass_b_finish<true, MON>(w, tl, txy, C, Cn, ws, js, vx, vy, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn, mon);
     }
   } else if (active) {
     double xi, yi, Pi;
     idn = idi;
-    const PairSums ps = pass_b_pairs<NOISE, false>(w, tl, txy, tss, tP, self, Cn, idi, js, x, y, eta, offById, P, sx, sy, xi, yi, Pi);
-    pass_b_finish<false>(w, tl, txy, C, Cn, ws, js, vx, vy, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn);
+    const PairSums ps = pass_b_pairs<NOISE, false, MON>(w, tl, txy, tss, tP, self, Cn, idi, js, x, y, eta, offById, P, sx, sy, xi, yi, Pi);
+    pass_b_finish<false, MON>(w, tl, txy, C, Cn, ws, js, vx, vy, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn, mon);
   }
   SC_STAMP(1, 5);
+  if constexpr (MON) {  // sums over the wave, one atomic per wave and phase; [kMonPhases] counts the particles
+    double cnt = active ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k <= kMonPhases; ++k) {
+      double v = k < kMonPhases ? (active ? mon[k] : 0.0) : cnt;
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      if ((t & 63) == 0 && v != 0.0) atomicAdd(&monitor[k], v);
+    }
+  }
   if (FUSED) {
     int cnext = -1, wsn = -1;
     const double xp = xn, yp = yn;  // as integrated: what a halo message carries (the receiver runs its own K1)

@@ -274,6 +274,38 @@ class Engine:
         N.check(self._lib.sc_owned_count(self._ctx, C.byref(n)))
         return n.value
 
+    # -- force monitor
+    def enable_force_monitor(self, on: bool = True) -> None:
+        N.check(self._lib.sc_enable_force_monitor(self._ctx, 1 if on else 0))
+
+    def force_monitor(self):
+        """-> (sum of |dv| per phase (6,), particles summed) since the last call; synchronises."""
+        sums = np.zeros(6)
+        n = C.c_int64(0)
+        N.check(self._lib.sc_get_force_monitor(self._ctx, N.dptr(sums), C.byref(n)))
+        return sums, n.value
+
+    # -- checkpoint
+    def checkpoint_begin(self) -> None:
+        N.check(self._lib.sc_checkpoint_begin(self._ctx))
+
+    def checkpoint_finish(self, room: int | None = None):
+        """-> dict(particles, velocities, ids, tick, next_id, rng) of the state sc_checkpoint_begin captured."""
+        room = self.capacity if room is None else int(room)
+        xy, vxy = np.empty((room, 2)), np.empty((room, 2))
+        ids = np.empty(room, dtype=np.int64)
+        n, tick, nid, pos = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int32(-1)
+        key = np.zeros(624, dtype=np.uint32)
+        N.check(self._lib.sc_checkpoint_finish(self._ctx, N.dptr(xy), N.dptr(vxy), N.i64ptr(ids), room, C.byref(n),
+                                               C.byref(tick), C.byref(nid), key.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                               C.byref(pos)))
+        k = n.value
+        return dict(particles=xy[:k].copy(), velocities=vxy[:k].copy(), ids=ids[:k].copy(), tick=tick.value,
+                    next_id=nid.value, rng=(key, pos.value) if pos.value >= 0 else None)
+
+    def restore_counters(self, tick: int, next_id: int) -> None:
+        N.check(self._lib.sc_restore_counters(self._ctx, int(tick), int(next_id)))
+
     # -- NumPy's global MT19937 stream on the device
     def rng_set_state(self, key, pos: int) -> None:
         """Hand the stream of `np.random.get_state()` (624-word key, position) to the device."""

@@ -8,7 +8,9 @@ mutating the loaded config in place, variant after variant -- and runs ``ticks_t
 for each.  Instead of rendering, a variant's recording is the particle state itself: where the
 reference writes config.yaml + AVI + GIF (playback.py:109-118) this writes config.yaml + state.npz
 (positions, pressure and segments every ``--record-every`` ticks), the state dump the reference
-left commented out (playback.py:112-113).
+left commented out (playback.py:112-113).  ``--checkpoint-every K`` also writes resumable checkpoints
+(``checkpoint_<tick>.npz``: `Crate.begin_checkpoint` captures the state on the device and sends it to pinned host
+memory on a side stream while the following ticks run); ``--resume FILE`` continues such a run.
 """
 from __future__ import annotations
 
@@ -63,14 +65,19 @@ class HeadlessPlayback:
     """`Playback` minus pygame: owns a `Crate`, ticks it, records state instead of frames."""
 
     def __init__(self, config: Config, recording_dir_path: Optional[Path] = None, *, noise: str = "host",
-                 record_every: int = 10, device: int = 0) -> None:
+                 record_every: int = 10, device: int = 0, checkpoint_every: int = 0,
+                 resume: Optional[Path] = None) -> None:
         self.config = config
         if recording_dir_path is None:
             stamp = datetime.now().strftime("%Y%m%d_%H%M%S")
             self.recording_dir_path = Path(config.playback_config.recording_output_dir_path) / stamp
         else:
             self.recording_dir_path = Path(recording_dir_path)
-        self.crate = Crate(config.world_config, noise=noise, device=device)
+        self.crate = (Crate.from_checkpoint(resume, device=device) if resume is not None
+                      else Crate(config.world_config, noise=noise, device=device))
+        self.checkpoint_every = max(int(checkpoint_every), 0)
+        self.checkpoints: list[Path] = []
+        self._checkpoint_tick = None
         self.record_every = max(int(record_every), 1)
         self.frames: list[dict] = []
         self.done = False
@@ -81,16 +88,30 @@ class HeadlessPlayback:
         t0 = time.perf_counter()
         for _ in range(int(n)):
             self.crate.physics_tick()
+            if self.checkpoint_every and self.crate.tick % self.checkpoint_every == 0:
+                self._collect_checkpoint()        # the previous one has long arrived
+                self.crate.begin_checkpoint()     # returns at once; the transfer overlaps the next ticks
+                self._checkpoint_tick = self.crate.tick
             if self.crate.tick % self.record_every == 0:
                 self.frames.append({"tick": self.crate.tick, "particles": self.crate.particles.copy(),
                                     "pressure": self.crate.particles_pressure.copy(),
                                     "segments": self.crate.segments.copy()})
             if self.done:
                 break
+        self._collect_checkpoint()
         self.crate.synchronize()
         self.seconds = time.perf_counter() - t0
         if self.config.playback_config.save_recording:
             self.save_recording(self.recording_dir_path)
+
+    def _collect_checkpoint(self) -> None:
+        if self._checkpoint_tick is None:
+            return
+        self.recording_dir_path.mkdir(exist_ok=True, parents=True)
+        path = self.recording_dir_path / f"checkpoint_{self._checkpoint_tick:06d}.npz"
+        self.crate.finish_checkpoint(path)
+        self.checkpoints.append(path)
+        self._checkpoint_tick = None
 
     def save_recording(self, out_dir: Path) -> None:
         out_dir.mkdir(exist_ok=True, parents=True)
@@ -106,14 +127,16 @@ class HeadlessPlayback:
 
 
 def main(config_file_path, play_recording: Optional[Path] = None, *, variants: Optional[int] = None,
-         ticks: Optional[int] = None, noise: str = "host", record_every: int = 10) -> list[dict]:
+         ticks: Optional[int] = None, noise: str = "host", record_every: int = 10, checkpoint_every: int = 0,
+         resume: Optional[Path] = None) -> list[dict]:
     config = load_config(config_file_path=config_file_path)
     summary = []
     for k, variant in enumerate(config_options(options, config)):
         if variants is not None and k >= variants:
             break
         out = Path(play_recording) / f"variant_{k:02d}" if play_recording is not None else None
-        playback = HeadlessPlayback(config=variant, recording_dir_path=out, noise=noise, record_every=record_every)
+        playback = HeadlessPlayback(config=variant, recording_dir_path=out, noise=noise, record_every=record_every,
+                                    checkpoint_every=checkpoint_every, resume=resume if k == 0 else None)
         playback.run_live_simulation(ticks)
         summary.append({"variant": k, "ticks": playback.crate.tick, "particles": playback.crate.particle_count,
                         "seconds": playback.seconds,
@@ -129,8 +152,10 @@ if __name__ == "__main__":
     ap.add_argument("play_recording", type=Path, nargs="?", default=None)
     ap.add_argument("--variants", type=int, default=None, help="stop after this many of the 48 combinations")
     ap.add_argument("--ticks", type=int, default=None, help="override playback.ticks_to_record")
-    ap.add_argument("--noise", default="host", choices=["host", "counter", "none"])
+    ap.add_argument("--noise", default="host", choices=["host", "host-sync", "counter", "none"])
     ap.add_argument("--record-every", type=int, default=10)
+    ap.add_argument("--checkpoint-every", type=int, default=0, help="write a resumable checkpoint every K ticks (0 = never)")
+    ap.add_argument("--resume", type=Path, default=None, help="continue the first variant from this checkpoint file")
     a = ap.parse_args()
     main(a.config_file_path, a.play_recording, variants=a.variants, ticks=a.ticks, noise=a.noise,
-         record_every=a.record_every)
+         record_every=a.record_every, checkpoint_every=a.checkpoint_every, resume=a.resume)

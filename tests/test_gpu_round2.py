@@ -159,3 +159,131 @@ def test_sources_on_the_device_respect_max_particles_and_capacity(sc):
     assert 0 < crate.particle_count <= 64
     ids = crate.engine.download()[3]
     assert ids.max() > 1000 and len(np.unique(ids)) == len(ids)  # far more particles than the box holds went through
+
+
+# ------------------------------------------------------------------ checkpoint / resume (N3)
+@pytest.mark.parametrize("noise", ["host", "host-sync", "counter"])
+def test_resume_from_checkpoint_is_bit_equal(sc, tmp_path, noise):
+    """40 ticks in one go against 20 ticks, save, a NEW crate from the file, 20 more: particles, ids, pressure, walls
+    and -- for the MT19937 modes -- the random stream continue exactly (wave_machine.yaml: a particle source that
+    is still emitting and a motored wall)."""
+    a = sc.Crate(scene(sc, "wave_machine"), noise=noise, noise_seed=3)
+    for _ in range(40):
+        a.physics_tick()
+    want = a.engine.download()
+    want_segments, want_draw = a.segments.copy(), None
+    if noise != "counter":
+        a.sync_host_rng()
+        want_draw = np.random.rand(3)
+
+    b = sc.Crate(scene(sc, "wave_machine"), noise=noise, noise_seed=3)
+    for _ in range(20):
+        b.physics_tick()
+    b.gravity = np.array([0.0, 9.8])  # coefficients travel as they stand (here unchanged)
+    b.save_checkpoint(tmp_path / "ck.npz")
+    np.random.seed(99)  # whatever happens to the global stream in between must not matter
+    c = sc.Crate.from_checkpoint(tmp_path / "ck.npz")
+    assert c.tick == 20 and c.particle_count == b.particle_count
+    assert np.array_equal(c.particles, b.particles) and np.array_equal(c.segments, b.segments)
+    for _ in range(20):
+        c.physics_tick()
+    got = c.engine.download()
+    assert c.tick == a.tick == 40
+    for x, y in zip(got, want):
+        assert np.array_equal(x, y)
+    assert np.array_equal(c.segments, want_segments)
+    if want_draw is not None:
+        c.sync_host_rng()
+        assert np.array_equal(np.random.rand(3), want_draw)
+
+
+def test_checkpoint_transfer_overlaps_later_ticks(sc, tmp_path):
+    """begin_checkpoint returns at once; ticks that follow do not disturb what it captured."""
+    n = 20000
+    p, v, d = synthetic(n, seed=8)
+    crate = sc.Crate(wave_world(sc, d, 0.1), noise="counter", noise_seed=2, capacity=n + 16)
+    crate.particles = p
+    crate.particle_velocities = v
+    crate.run(3)
+    at_begin = crate.engine.download()
+    segments = crate.segments.copy()
+    crate.begin_checkpoint()
+    crate.run(4)                      # runs while the snapshot travels
+    crate.finish_checkpoint(tmp_path / "ck.npz")
+    moved_on = crate.engine.download()
+    assert not np.array_equal(moved_on[0], at_begin[0])
+    back = sc.Crate.from_checkpoint(tmp_path / "ck.npz")
+    assert back.tick == 3
+    assert np.array_equal(back.particles, at_begin[0]) and np.array_equal(back.particle_velocities, at_begin[1])
+    assert np.array_equal(back.segments, segments)
+    back.run(4)
+    for x, y in zip(back.engine.download(), moved_on):
+        assert np.array_equal(x, y)
+    with pytest.raises(RuntimeError):
+        crate.finish_checkpoint(tmp_path / "none.npz")
+
+
+# ------------------------------------------------------------------ the Forces block of the HUD (N4)
+def test_force_monitor_matches_the_oracle_phases(sc):
+    """Mean |dv| per force phase as the reference's ForceMonitor takes it (force_monitor.py:23-33 around
+    crate.py:110-123), from the force kernel's side sums, against the oracle's per-phase velocities; and the monitor
+    changes no result."""
+    from oracle.scene import OracleCrate
+    from oracle.tick import counter_noise_key, counter_noise_u01, tick_core
+    from oracle.world import World
+    n = 20000
+    p, v, d = synthetic(n, seed=31, margin=0.0, vel=20.0)  # fast, up to the walls: every phase has work
+    wc = wave_world(sc, d, 0.1)
+    wc.coefficients["max_particles"] = n
+    plain = sc.Crate(copy.deepcopy(wc), noise="counter", noise_seed=6, capacity=n + 16)
+    hud = sc.Crate(copy.deepcopy(wc), noise="counter", noise_seed=6, capacity=n + 16)
+    hud.show_forces(True)
+    for c in (plain, hud):
+        c.particles = p
+        c.particle_velocities = v
+        c.physics_tick()
+    for x, y in zip(plain.engine.download(), hud.engine.download()):
+        assert np.array_equal(x, y)
+    orc = OracleCrate(World(wc.rigid_bodies, [], dict(wc.coefficients)))
+    for b in orc.rigid_bodies:
+        b.advance(orc.coef["dt"])
+    from oracle.tick import remove_outside
+    ids = np.arange(n)
+    p1, v1, ids = remove_outside(p, v, orc.coef["particle_radius"], ids)
+    out = tick_core(p1, v1, orc.segments, orc.body_states(), orc.coef, eta_u01=counter_noise_u01(ids, counter_noise_key(6, 0)))
+    dt, g = orc.coef["dt"], np.asarray(orc.coef["gravity"], dtype=np.float64)
+    norm = lambda a: float(np.mean(np.sqrt(a[:, 0] ** 2 + a[:, 1] ** 2)))  # noqa: E731
+    want = {
+        "tension": norm(out["v_after_tension"] - v1),
+        "gravity": float(np.sqrt(((dt * g) ** 2).sum())),
+        "pressure": norm(out["v_after_pressure"] - (out["v_after_tension"] + dt * g[None])),
+        "viscosity": norm(out["v_after_viscosity"] - out["v_after_pressure"]),
+        "wall_bounce": norm(out["v_after_bounce"] - out["v_after_viscosity"]),
+        "continuous_collision": norm(out["v_after_bounce"] * out["ccd_factor"][:, None] - out["v_after_bounce"]),
+    }
+    assert want["wall_bounce"] > 0 and want["continuous_collision"] > 0
+    for name, value in want.items():
+        got = hud._force_ema[name] / 0.2  # the first tick of the EMA: 0.2 x the tick's mean
+        assert got == pytest.approx(value, rel=1e-7, abs=1e-13), name
+    text = hud.debug_prints
+    assert "Forces:" in text and text.index("Timing:") < text.index("Forces:") < text.index("- dt:")
+    for name in want:
+        assert f"{name}:" in text
+    hud.show_forces(False)
+    hud.physics_tick()
+    assert "Forces:" not in hud.debug_prints
+
+
+def test_headless_driver_checkpoints_and_resumes(sc, tmp_path):
+    """`python -m sand_crate_amd.main` with --checkpoint-every: the files it writes while ticking resume to the same
+    final state as the uninterrupted run."""
+    from sand_crate_amd.main import main
+    whole = main("config/stirring_cup.yaml", tmp_path / "a", variants=1, ticks=60, checkpoint_every=20)
+    files = sorted((tmp_path / "a" / "variant_00").glob("checkpoint_*.npz"))
+    assert [f.name for f in files] == ["checkpoint_000020.npz", "checkpoint_000040.npz", "checkpoint_000060.npz"]
+    rest = main("config/stirring_cup.yaml", tmp_path / "b", variants=1, ticks=20, resume=files[1], record_every=20)
+    assert rest[0]["ticks"] == 60 and rest[0]["particles"] == whole[0]["particles"]
+    end_a = sc.Crate.from_checkpoint(files[2])
+    rec_b = np.load(tmp_path / "b" / "variant_00" / "state.npz")
+    assert rec_b["ticks"].tolist() == [60]
+    assert np.array_equal(rec_b["particles_0"], end_a.particles)
