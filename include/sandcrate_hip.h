@@ -288,6 +288,22 @@ int sc_rng_set_state(sc_ctx* ctx, const uint32_t* key_624, int32_t position);
 int sc_rng_get_state(sc_ctx* ctx, uint32_t* key_624, int32_t* position);
 int sc_emit_particles(sc_ctx* ctx, const sc_source* sources, int32_t n_sources, double dt, int64_t max_particles);
 
+/* Halo overlap (BASELINE.json configs[4]: "halo overlap on side HIP stream").  With it on, a tick whose successor
+ * was promised runs its force kernel in two launches: first the blocks that hold a particle within the halo band
+ * plus two columns of a cut -- the only ones that can pack halo records -- then the interior blocks; the exchange
+ * of the coming tick waits for the first launch only and runs on the context's side stream next to the second.
+ *   sc_halo_exchange        does both waits itself (RCCL calls go to the side stream);
+ *   sc_halo_overlap_begin   for other transports: the side stream waits for what the coming message depends on
+ *                           (`peer`, optional: and for what that context's message depends on -- in-process chains);
+ *                           the caller then enqueues its copies / sends on sc_side_stream;
+ *   sc_halo_overlap_end     the context's stream waits for the side stream; sc_halo_unpack follows as usual.
+ * A particle of an interior block that ends the tick inside a band after all (it moved more than two columns) is
+ * not silently lost: SC_ERR_DOMAIN at the next synchronising call. */
+int sc_set_halo_overlap(sc_ctx* ctx, int on);
+int sc_side_stream(sc_ctx* ctx, void** hip_stream);
+int sc_halo_overlap_begin(sc_ctx* ctx, sc_ctx* peer);
+int sc_halo_overlap_end(sc_ctx* ctx);
+
 /* Synchronises.  Live particles stored in this context (dead ghost copies excluded); summed over
  * the ranks this is the global particle count. */
 int sc_owned_count(sc_ctx* ctx, int64_t* n);

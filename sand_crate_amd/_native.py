@@ -102,6 +102,10 @@ SIGNATURES = {
     "sc_comm_destroy": (C.c_int, [_P]),
     "sc_halo_exchange": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P, C.c_int64, _P, C.c_int64, C.c_int32]),
     "sc_owned_count": (C.c_int, [_P, _I64]),
+    "sc_set_halo_overlap": (C.c_int, [_P, C.c_int]),
+    "sc_side_stream": (C.c_int, [_P, C.POINTER(_P)]),
+    "sc_halo_overlap_begin": (C.c_int, [_P, _P]),
+    "sc_halo_overlap_end": (C.c_int, [_P]),
     "sc_enable_force_monitor": (C.c_int, [_P, C.c_int]),
     "sc_get_force_monitor": (C.c_int, [_P, _D, _I64]),
     "sc_checkpoint_begin": (C.c_int, [_P]),

@@ -82,6 +82,10 @@ struct sc_ctx {
   double* keyX = nullptr;
   int* keyId = nullptr;
   int* tileBounds = nullptr;
+  int* tileBand = nullptr;  // per block of pass A / B: holds a particle that may be packed into a halo message
+  // halo overlap (sc_set_halo_overlap): the exchange runs on the side stream between the two launches of pass B
+  bool overlap = false, band_pending = false;
+  hipEvent_t ev_band = nullptr, ev_xchg = nullptr;
   int *cellCount = nullptr, *cellStart = nullptr, *blockSums = nullptr, *blockOff = nullptr, *sortedStamp = nullptr;
   int* bigList = nullptr;
   RcclComm comm = nullptr;  // RCCL communicator of the slab chain (sc_comm_init), or null
@@ -372,6 +376,9 @@ int check_flags(int flags) {
   if (flags & F_OUT_OF_GRID) return fail(SC_ERR_DOMAIN, "a particle left the cell grid; it was dropped");
   if (flags & F_HALO_OVERFLOW) return fail(SC_ERR_CAPACITY, "a halo buffer was too small; ghost particles were lost");
   if (flags & F_CAPACITY) return fail(SC_ERR_CAPACITY, "received halo particles exceed the context capacity");
+  if (flags & F_HALO_LATE)
+    return fail(SC_ERR_DOMAIN, "a particle moved more than %d columns in one tick and missed the overlapped halo message",
+                kBandMargin);
   return SC_OK;
 }
 
@@ -434,7 +441,7 @@ template <int NOISE, bool ENUM, bool DENS, int CAP>
 void launch_pass_a_cap(sc_ctx* c) {
   hipLaunchKernelGGL((k_pass_a<NOISE, ENUM, DENS, CAP>), dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters,
                      c->x[1], c->y[1], c->id[1], c->cellT, Buckets{c->cellStart, c->blockOff}, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta, c->offById,
-                     c->P, c->sx, c->sy, c->tileBounds);
+                     c->P, c->sx, c->sy, c->tileBounds, c->tileBand);
 }
 
 template <int NOISE, bool ENUM, bool DENS>
@@ -453,21 +460,28 @@ void launch_pass_a(sc_ctx* c, int kernel_id) {
 }
 
 template <int NOISE, bool FUSED, bool MON = false>
-void launch_pass_b(sc_ctx* c, const WallInputs& wn) {
+void launch_pass_b(sc_ctx* c, const WallInputs& wn, int part = 0) {
   Bracket br(c, K_FORCE);
   const int cur = (int)(c->tick & 1), nxt = cur ^ 1;
   hipLaunchKernelGGL((k_pass_b<NOISE, FUSED, MON>), dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters, c->x[1],
                      c->y[1], c->vx[1], c->vy[1], c->id[1], c->wslotT, c->cellT, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta,
                      c->offById, c->P, c->sx, c->sy, c->wrec[cur], c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0],
                      c->tileBounds, c->bigHintDev, wn, c->cellS, c->wslotS, c->cellCount, c->wrec[nxt], c->haloL, c->haloR,
-                     c->haloCap, c->monitor);
+                     c->haloCap, c->monitor, c->tileBand, part);
 }
 
 template <int NOISE>
 void launch_pass_b_any(sc_ctx* c, bool fused, const WallInputs& wn) {
-  if (c->monitor_on)
+  if (c->monitor_on) {
     launch_pass_b<NOISE, false, true>(c, wn);
-  else if (fused)
+  } else if (fused && c->slab && c->overlap && c->haloL && (c->has_left || c->has_right)) {
+    // halo overlap: the blocks that may pack halo records first; once they are done (ev_band) the exchange of the
+    // coming tick may start on the side stream while the interior blocks run
+    launch_pass_b<NOISE, true>(c, wn, 1);
+    (void)hipEventRecord(c->ev_band, c->stream);
+    c->band_pending = true;
+    launch_pass_b<NOISE, true>(c, wn, 2);
+  } else if (fused)
     launch_pass_b<NOISE, true>(c, wn);
   else
     launch_pass_b<NOISE, false>(c, wn);
@@ -512,6 +526,8 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
   if (e == hipSuccess) e = dalloc(&c->keyX, n);
   if (e == hipSuccess) e = dalloc(&c->keyId, n);
   if (e == hipSuccess) e = dalloc(&c->tileBounds, 6 * (n / kTileW + 2));
+  if (e == hipSuccess) e = dalloc(&c->tileBand, n / kTileW + 2);
+  if (e == hipSuccess) e = hipMemsetAsync(c->tileBand, 0, (n / kTileW + 2) * sizeof(int), c->stream);
   if (e == hipSuccess) e = dalloc(&c->bigList, (size_t)kMaxBig);
   if (e == hipSuccess) e = dalloc(&c->rankAcc, n);
   if (e == hipSuccess) e = hipMemsetAsync(c->rankAcc, 0, n * sizeof(int), c->stream);
@@ -551,7 +567,9 @@ int sc_destroy(sc_ctx* c) {
     (void)hipFree(c->vy[s]);
     (void)hipFree(c->id[s]);
   }
-  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->rankAcc, c->wrec[0], c->wrec[1],
+  if (c->ev_band) (void)hipEventDestroy(c->ev_band);
+  if (c->ev_xchg) (void)hipEventDestroy(c->ev_xchg);
+  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->tileBand, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->rankAcc, c->wrec[0], c->wrec[1],
                   c->nbr, c->nbr16, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
                   c->stage_xy, c->stage_vxy, c->stage_ids, c->owned_out, c->colHist, c->rng, c->monitor,
                   c->snap_d[0], c->snap_d[1], c->snap_d[2], c->snap_d[3], c->snap_id_d, c->snap_rng_d};
@@ -1242,6 +1260,7 @@ int sc_halo_pack(sc_ctx* c, double* dev_left, double* dev_right, int64_t cap_rec
   int rc = make_world(c);
   if (rc) return rc;
   if (c->prebinned) return fail(SC_ERR_STATE, "the halo message of the promised tick was packed by sc_step_finish");
+  c->band_pending = false;  // this message depends on the kernel below, not on a split force kernel
   c->haloL = dev_left;  // stay bound: with sc_set_next_inputs, sc_step_finish packs the next message itself
   c->haloR = dev_right;
   c->haloCap = (int)cap_records;
@@ -1282,6 +1301,62 @@ int sc_halo_unpack(sc_ctx* c, const double* from_left, int64_t left_records, con
     int rc_ = (expr);                                                                       \
     if (rc_ != 0) return fail(SC_ERR_HIP, "RCCL: %s failed: %s", #expr, rccl_error(rc_)); \
   } while (0)
+
+static int ensure_side_stream(sc_ctx* c) {
+  if (!c->side_stream) HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+  if (!c->ev_band) HIPCHK(hipEventCreateWithFlags(&c->ev_band, hipEventDisableTiming));
+  if (!c->ev_xchg) HIPCHK(hipEventCreateWithFlags(&c->ev_xchg, hipEventDisableTiming));
+  return SC_OK;
+}
+
+int sc_set_halo_overlap(sc_ctx* c, int on) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  if (c->in_step) return fail(SC_ERR_STATE, "halo overlap cannot change inside a tick");
+  if (on && !c->slab) return fail(SC_ERR_STATE, "sc_set_slab first");
+  HIPCHK(hipSetDevice(c->device));
+  if (on) {
+    int rc = ensure_side_stream(c);
+    if (rc) return rc;
+  }
+  c->overlap = on != 0;
+  return SC_OK;
+}
+
+int sc_side_stream(sc_ctx* c, void** stream) {
+  if (!c || !stream) return fail(SC_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(c->device));
+  int rc = ensure_side_stream(c);
+  if (rc) return rc;
+  *stream = (void*)c->side_stream;
+  return SC_OK;
+}
+
+// side stream <- everything the halo message of the coming tick depends on (the band blocks of pass B when the last
+// tick packed it, else all work queued so far); `peer`: also what that context's message depends on
+int sc_halo_overlap_begin(sc_ctx* c, sc_ctx* peer) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  HIPCHK(hipSetDevice(c->device));
+  int rc = ensure_side_stream(c);
+  if (rc) return rc;
+  for (sc_ctx* q : {c, peer}) {
+    if (!q) continue;
+    if (q != c && (rc = ensure_side_stream(q))) return rc;
+    if (!q->band_pending) HIPCHK(hipEventRecord(q->ev_band, q->stream));  // no split pass B before: wait for all of it
+    HIPCHK(hipStreamWaitEvent(c->side_stream, q->ev_band, 0));
+  }
+  return SC_OK;
+}
+
+// context's stream <- what was enqueued on the side stream since sc_halo_overlap_begin (the received buffers)
+int sc_halo_overlap_end(sc_ctx* c) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  if (!c->side_stream || !c->ev_xchg) return fail(SC_ERR_STATE, "sc_halo_overlap_begin first");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipEventRecord(c->ev_xchg, c->side_stream));
+  HIPCHK(hipStreamWaitEvent(c->stream, c->ev_xchg, 0));
+  c->band_pending = false;
+  return SC_OK;
+}
 
 int sc_comm_available(const char* rccl_path) {
   if (rccl_load(rccl_path)) return fail(SC_ERR_HIP, "%s", rccl_api().error.c_str());
@@ -1334,20 +1409,27 @@ int sc_halo_exchange(sc_ctx* c, const double* send_left, int64_t send_left_recor
   auto doubles = [](int64_t records) { return (size_t)(records + 1) * kHaloFields; };  // + the header record
   const RcclApi& r = rccl_api();
   HIPCHK(hipSetDevice(c->device));
+  hipStream_t xs = c->stream;
+  if (c->overlap) {  // on the side stream, next to the interior blocks of the last pass B
+    int rc0 = sc_halo_overlap_begin(c, nullptr);
+    if (rc0) return rc0;
+    xs = c->side_stream;
+  }
   RCCLCHK(r.GroupStart());
   int rc = 0;
   // posting order is the same on every rank (left pair, then right pair): rank k's right pair meets rank k+1's left pair
   if (left_rank >= 0) {
-    if (!rc) rc = r.Send(send_left, doubles(send_left_records), kRcclDouble, left_rank, c->comm, c->stream);
-    if (!rc) rc = r.Recv(recv_left, doubles(recv_left_records), kRcclDouble, left_rank, c->comm, c->stream);
+    if (!rc) rc = r.Send(send_left, doubles(send_left_records), kRcclDouble, left_rank, c->comm, xs);
+    if (!rc) rc = r.Recv(recv_left, doubles(recv_left_records), kRcclDouble, left_rank, c->comm, xs);
   }
   if (right_rank >= 0) {
-    if (!rc) rc = r.Send(send_right, doubles(send_right_records), kRcclDouble, right_rank, c->comm, c->stream);
-    if (!rc) rc = r.Recv(recv_right, doubles(recv_right_records), kRcclDouble, right_rank, c->comm, c->stream);
+    if (!rc) rc = r.Send(send_right, doubles(send_right_records), kRcclDouble, right_rank, c->comm, xs);
+    if (!rc) rc = r.Recv(recv_right, doubles(recv_right_records), kRcclDouble, right_rank, c->comm, xs);
   }
   const int rc_end = r.GroupEnd();
   if (rc) return fail(SC_ERR_HIP, "RCCL: send/recv failed: %s", rccl_error(rc));
   if (rc_end) return fail(SC_ERR_HIP, "RCCL: ncclGroupEnd failed: %s", rccl_error(rc_end));
+  if (c->overlap) return sc_halo_overlap_end(c);
   return SC_OK;
 }
 

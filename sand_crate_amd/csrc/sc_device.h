@@ -88,7 +88,9 @@ enum Counter {
   C_COUNT = 12
 };
 
-enum Flag { F_OUT_OF_GRID = 1, F_NAN = 2, F_HALO_OVERFLOW = 4, F_CAPACITY = 8 };
+enum Flag { F_OUT_OF_GRID = 1, F_NAN = 2, F_HALO_OVERFLOW = 4, F_CAPACITY = 8, F_HALO_LATE = 16 };
+
+constexpr int kBandMargin = 2;  // columns a particle may move in one tick and still be packed in time (halo overlap)
 
 constexpr int kGhostBit = 1 << 30;  // set in a particle's packed cell index when it is a ghost
 constexpr int kCellMask = kGhostBit - 1;

@@ -703,15 +703,21 @@ __device__ __forceinline__ int halo_slot(bool want, double* __restrict__ buf) {
 }
 
 // `d`, own_lo .. has_right: the slab of the COMING tick.  `on`: this lane holds a stored, live particle.
+// `late`: the message has already left (halo overlap: this is an interior tile); a particle that belongs in it
+// after all moved further than the band margin allows -- flagged, never silently dropped.
 __device__ __forceinline__ void halo_pack_one(bool on, double px, double py, double pvx, double pvy, int pid, double d,
                                               long long own_lo, long long own_hi, int halo, int has_left,
                                               int has_right, double* __restrict__ left, double* __restrict__ right,
-                                              int cap, int* __restrict__ counters) {
+                                              int cap, int* __restrict__ counters, bool late = false) {
   bool toL = false, toR = false;
   if (on && fabs(px) < 1e300) {  // not a dead ghost copy (x = +inf), not NaN
     const long long col = (long long)floor(px / d);
     toL = has_left && col < own_lo + halo;
     toR = has_right && col >= own_hi - halo;
+  }
+  if (late) {
+    if (toL || toR) atomicOr(&counters[C_FLAGS], F_HALO_LATE);
+    return;
   }
   const int kl = halo_slot(toL, left), kr = halo_slot(toR, right);
   if (kl >= cap || kr >= cap) atomicOr(&counters[C_FLAGS], F_HALO_OVERFLOW);

@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(kTileW)
              const int* __restrict__ id, const int* __restrict__ cell, Buckets bk,
              int* __restrict__ nbr, unsigned short* __restrict__ nbr16, unsigned char* __restrict__ cnt, int cap,
              const double* __restrict__ eta, const int* __restrict__ offById, double* __restrict__ P, double* __restrict__ sx,
-             double* __restrict__ sy, const int* __restrict__ tileBounds) {
+             double* __restrict__ sy, const int* __restrict__ tileBounds, int* __restrict__ tileBand) {
   constexpr int kPad = SC_SCAN_BATCH - 1;  // a batched scan may read this far past either end of the tile
   __shared__ XY txy_padded[CAP + 2 * kPad];
   XY* const txy = txy_padded + kPad;
@@ -436,6 +436,20 @@ __global__ void __launch_bounds__(kTileW)
   if (i0 >= n) return;
   const int m = min(kTileW, n - i0);
   const bool live = t < m;
+
+  // slabs: does this block hold a particle that may end the tick in a halo band (its column within the band
+  // plus kBandMargin of a cut)?  Pass B runs those blocks first and lets the halo exchange start while the
+  // interior blocks are still computing (sc_set_halo_overlap).
+  if (ENUM && w.slab) {
+    bool band = false;
+    if (live) {
+      const int c = cpacked & kCellMask;
+      const long long col = (long long)(c % w.ncols) + w.col0;
+      band = (w.has_left && col < w.own_lo + w.halo + kBandMargin) || (w.has_right && col >= w.own_hi - w.halo - kBandMargin);
+    }
+    const int any = __syncthreads_or(band);
+    if (t == 0) tileBand[tile_id] = any;
+  }
 
   // 1. the particle's own candidate ranges (cell -> six bucket boundaries)
   Tile tl;
@@ -695,7 +709,8 @@ __global__ void __launch_bounds__(kTileW)
              const int* __restrict__ tileBounds, volatile int* __restrict__ progress,
              WallInputs wn, int* __restrict__ cellS, int* __restrict__ wslotS, int* __restrict__ cellCount,
              double* __restrict__ wrec_next, double* __restrict__ haloL,
-             double* __restrict__ haloR, int haloCap, double* __restrict__ monitor) {
+             double* __restrict__ haloR, int haloCap, double* __restrict__ monitor, const int* __restrict__ tileBand,
+             int part) {
   static_assert(!(MON && FUSED), "the force monitor runs with the plain force kernel");
   __shared__ XY txy[kTileCapB];   // (x, y) of the tile; (vx, vy) once the pair loop is done
   __shared__ XY tss[kTileCapB];   // (sx, sy)
@@ -719,7 +734,9 @@ __global__ void __launch_bounds__(kTileW)
 #pragma unroll
   for (int s = 0; s < kMaxNbr; ++s) js[s] = nbr16[(size_t)s * cap + ic];
   const int n = counters[C_NT];
-  if (tile_id == 0 && t == 0) {
+  // part 1 / 2: the blocks with / without band particles only (halo overlap: two launches, the exchange starts
+  // between them); 0: all blocks
+  if (tile_id == 0 && t == 0 && part != 2) {
     counters[C_NS] = n;    // the storage arrays now hold the n live particles
     counters[C_SUMC] = 0;  // per-tick counters start the next tick at zero (sc_step_stats reads them
                            // between sc_step_begin and sc_step_finish, i.e. before this kernel)
@@ -730,6 +747,7 @@ __global__ void __launch_bounds__(kTileW)
     progress[2] = n;           // ... and sizes heuristics by a recent live count
   }
   if (i0 >= n) return;
+  if (part && (tileBand[tile_id] != 0) != (part == 1)) return;
   SC_STAMP(1, 1);
   const int m = min(kTileW, n - i0);
   const bool live = t < m;
@@ -842,7 +860,7 @@ __global__ void __launch_bounds__(kTileW)
     // k_halo_pack); a workgroup-uniform branch, every lane of the wave takes part
     if (wn.slab && haloL)
       halo_pack_one(active, xp, yp, vxn, vyn, idn, wn.d, w.own_lo, w.own_hi, w.halo, w.has_left, w.has_right, haloL,
-                    haloR, haloCap, counters);
+                    haloR, haloCap, counters, part == 2);
   }
   SC_STAMP(1, 6);
   if (live) {

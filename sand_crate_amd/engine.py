@@ -269,6 +269,21 @@ class Engine:
         N.check(self._lib.sc_halo_exchange(self._ctx, ptr(send_left), sl, ptr(recv_left), rl, int(left_rank),
                                            ptr(send_right), sr, ptr(recv_right), rr, int(right_rank)))
 
+    # -- halo overlap: the exchange on the side stream, next to the interior blocks of the force kernel
+    def set_halo_overlap(self, on: bool = True) -> None:
+        N.check(self._lib.sc_set_halo_overlap(self._ctx, 1 if on else 0))
+
+    def side_stream(self) -> int:
+        s = N._P()
+        N.check(self._lib.sc_side_stream(self._ctx, C.byref(s)))
+        return int(s.value or 0)
+
+    def halo_overlap_begin(self, peer: "Engine | None" = None) -> None:
+        N.check(self._lib.sc_halo_overlap_begin(self._ctx, peer._ctx if peer is not None else None))
+
+    def halo_overlap_end(self) -> None:
+        N.check(self._lib.sc_halo_overlap_end(self._ctx))
+
     def owned_count(self) -> int:
         n = C.c_int64(0)
         N.check(self._lib.sc_owned_count(self._ctx, C.byref(n)))

@@ -142,6 +142,8 @@ class HipSlabBackend:
         self._inputs = None
         self.packed_ahead = False
         self._promised = None
+        self.overlap = False
+        self._side = None
 
     def load(self, particles, velocities, ids) -> None:
         self.engine.upload_with_ids(particles, velocities, ids)
@@ -175,6 +177,16 @@ class HipSlabBackend:
 
     def column_histogram(self, col0: int, n_columns: int) -> np.ndarray:
         return self.engine.column_histogram(col0, n_columns)
+
+    def set_overlap(self, on: bool) -> None:
+        """Halo overlap: the exchange runs on the context's side stream next to the interior blocks of the force
+        kernel (sc_set_halo_overlap)."""
+        self.engine.set_halo_overlap(on)
+        self.overlap = bool(on)
+        self._side = self.torch.cuda.ExternalStream(self.engine.side_stream(), device=self.device) if on else None
+
+    def side_stream(self):
+        return self._side
 
     def bundled_rccl(self) -> str | None:
         """torch's own librccl, the fallback path for dlopen when no copy is loaded yet."""
@@ -213,7 +225,8 @@ class SlabCrate:
     def __init__(self, world_config, particles, velocities, *, device: int = 0, noise: str = "counter",
                  noise_seed: int = 0, group=None, backend=None, halo_capacity: int | None = None,
                  capacity: int | None = None, transport: str | None = None, rebalance_every: int = 0,
-                 cuts: list[int] | None = None, rank: int | None = None, world: int | None = None):
+                 cuts: list[int] | None = None, overlap: bool = True, rank: int | None = None,
+                 world: int | None = None):
         """`rank` / `world` given: a member of an in-process `SlabChain` (the chain moves the messages and adds the
         histograms); otherwise they come from torch.distributed."""
         import torch.distributed as dist
@@ -267,6 +280,9 @@ class SlabCrate:
         self._own_mask = own
         self.backend.load(p[own], v[own], ids)
         self.halo_capacity = int(halo_capacity)
+        self.overlap = bool(overlap) and self.world > 1 and hasattr(self.backend, "set_overlap")
+        if self.overlap:
+            self.backend.set_overlap(True)
         self._initial_slabs = list(self.slabs)
         self._now = None      # inputs of the coming tick, when the previous one promised them
         self._sizes = None    # message sizes of the coming exchange
@@ -397,8 +413,15 @@ class SlabCrate:
             for peer, send, recv in pairs:
                 ops.append(dist.P2POp(dist.isend, send, peer, self.group))
                 ops.append(dist.P2POp(dist.irecv, recv, peer, self.group))
-            for work in dist.batch_isend_irecv(ops):
-                work.wait()  # stream-ordered for NCCL: the current stream waits, the host does not
+            if self.overlap:  # on the side stream, next to the interior blocks of the last force kernel
+                be.engine.halo_overlap_begin()
+                with be.torch.cuda.stream(be.side_stream()):
+                    for work in dist.batch_isend_irecv(ops):
+                        work.wait()
+                be.engine.halo_overlap_end()
+            else:
+                for work in dist.batch_isend_irecv(ops):
+                    work.wait()  # stream-ordered for NCCL: the current stream waits, the host does not
 
     # -- one tick in phases (SlabChain interleaves them across its members)
     def _rebalance_due(self, tick: int) -> bool:
@@ -529,14 +552,14 @@ class SlabChain:
 
     def __init__(self, world_config, particles, velocities, n_slabs: int, *, device: int = 0, noise: str = "counter",
                  noise_seed: int = 0, halo_capacity: int | None = None, capacity: int | None = None,
-                 rebalance_every: int = 0, cuts: list[int] | None = None, backend_factory=None):
+                 rebalance_every: int = 0, cuts: list[int] | None = None, overlap: bool = True, backend_factory=None):
         self.members = []
         for k in range(n_slabs):
             backend = backend_factory(k) if backend_factory is not None else None
             self.members.append(SlabCrate(copy.deepcopy(world_config), particles, velocities, device=device, noise=noise,
                                           noise_seed=noise_seed, halo_capacity=halo_capacity, capacity=capacity,
-                                          rebalance_every=rebalance_every, cuts=cuts, rank=k, world=n_slabs,
-                                          backend=backend))
+                                          rebalance_every=rebalance_every, cuts=cuts, overlap=overlap, rank=k,
+                                          world=n_slabs, backend=backend))
         self.tick = 0
         self.message_records = []  # per tick: the records every message carried (left-to-right, then right-to-left)
 
@@ -547,15 +570,28 @@ class SlabChain:
     def _move_messages(self) -> None:
         words = lambda records: (records + 1) * HALO_FIELDS  # noqa: E731
         sent = []
+        overlap = all(m.overlap for m in self.members)
         for a, b in zip(self.members[:-1], self.members[1:]):
             to_right, from_left = a._sizes[2], b._sizes[1]
             to_left, from_right = b._sizes[0], a._sizes[3]
             if to_right != from_left or to_left != from_right:
                 raise RuntimeError(f"slabs {a.rank} and {b.rank} disagree on their message sizes: "
                                    f"{to_right} vs {from_left}, {to_left} vs {from_right}")
-            b.backend.recv_left[:words(to_right)].copy_(a.backend.send_right[:words(to_right)])
-            a.backend.recv_right[:words(to_left)].copy_(b.backend.send_left[:words(to_left)])
+            if overlap:  # each copy on the receiver's side stream, behind the band blocks of both ends
+                torch = a.backend.torch
+                b.engine.halo_overlap_begin(a.engine)
+                with torch.cuda.stream(b.backend.side_stream()):
+                    b.backend.recv_left[:words(to_right)].copy_(a.backend.send_right[:words(to_right)], non_blocking=True)
+                a.engine.halo_overlap_begin(b.engine)
+                with torch.cuda.stream(a.backend.side_stream()):
+                    a.backend.recv_right[:words(to_left)].copy_(b.backend.send_left[:words(to_left)], non_blocking=True)
+            else:
+                b.backend.recv_left[:words(to_right)].copy_(a.backend.send_right[:words(to_right)])
+                a.backend.recv_right[:words(to_left)].copy_(b.backend.send_left[:words(to_left)])
             sent += [to_right, to_left]
+        if overlap:
+            for m in self.members:
+                m.engine.halo_overlap_end()
         self.message_records.append(sent)
 
     def run(self, n_ticks: int) -> None:

@@ -207,3 +207,44 @@ def test_rebalanced_cuts_on_the_gpu(sc):
     chain2.synchronize()
     assert chain2.members[0].rebalances >= 3 and chain2.slabs == chain.slabs
     assert_chain_equals_single(chain2, single)
+
+
+def test_halo_overlap_splits_the_force_kernel_and_changes_nothing(sc):
+    """Halo overlap (configs[4]): with the next tick promised the force kernel runs as two launches -- the blocks that
+    may pack halo records, then the interior -- and the messages are moved on the side streams in between.  Same
+    particles as without overlap and as the single domain; both launches show up in the kernel timing."""
+    from sand_crate_amd.slab import SlabChain
+    n, ticks = 300000, 6
+    wc, p, v, d = bench_world(n)
+    single, _ = single_domain(sc, wc, p, v, ticks)
+    for overlap in (True, False):
+        chain = SlabChain(copy.deepcopy(wc), p, v, 3, noise="counter", noise_seed=1, overlap=overlap)
+        assert all(m.overlap == overlap for m in chain.members)
+        eng = chain.members[1].engine
+        eng.reset_timing()
+        eng.enable_timing(True)
+        chain.run(ticks)
+        chain.synchronize()
+        eng.enable_timing(False)
+        launches = eng.timing()["force_integrate"][1]
+        assert launches == (2 * (ticks - 1) + 1 if overlap else ticks)  # the last tick of a run() promises nothing
+        assert_chain_equals_single(chain, single)
+
+
+def test_particle_too_fast_for_the_overlapped_message_is_reported(sc):
+    """An interior block whose particle ends the tick inside a halo band although it started more than two columns
+    away from it: the message had left -- SC_ERR_DOMAIN, not a silently missing ghost."""
+    from sand_crate_amd._native import NativeError
+    from sand_crate_amd.slab import SlabChain, column_of
+    n = 120000
+    wc, p, v, d = bench_world(n)
+    chain = SlabChain(copy.deepcopy(wc), p, v, 2, noise="counter", noise_seed=1, overlap=True)
+    cut = chain.slabs[1][0]
+    col = column_of(p[:, 0], d)
+    v = v.copy()
+    fast = np.flatnonzero((col > cut - 40) & (col < cut - 30))[:50]  # well inside slab 0 ...
+    v[fast, 0] = 35 * d / wc.coefficients["dt"]                      # ... and 35 columns to the right in one tick
+    chain = SlabChain(copy.deepcopy(wc), p, v, 2, noise="counter", noise_seed=1, overlap=True)
+    chain.run(3)
+    with pytest.raises(NativeError, match="missed the overlapped halo message"):
+        chain.synchronize()
