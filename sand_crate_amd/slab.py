@@ -294,7 +294,11 @@ class SlabCrate:
             raise ValueError("transport must be 'rccl' or 'torch'")
         if (want == "rccl" and self.world > 1 and not self._chained and not self._host_staged
                 and hasattr(self.backend, "exchange_rccl")):
-            self._try_rccl()
+            self._try_rccl()  # with overlap on, its proof exchange also proves RCCL on the side stream
+        if self.overlap and not self._chained and self.transport != "rccl" and os.environ.get("SANDCRATE_OVERLAP") != "force":
+            # the torch.distributed fallback is the safety net: keep it on the context's own stream
+            self.backend.set_overlap(False)
+            self.overlap = False
 
     def reload(self, particles, velocities) -> None:
         """Start over from a state with the SAME particle positions as the one this object was built with (same
