@@ -82,7 +82,7 @@ class Crate:
         np.random.seed(0)  # the reference seeds the global legacy RNG here (crate.py:22)
         self.tick: int = 0
         self.debug_arrows: list = []
-        self.debug_prints: str = ""
+        self._debug_prints: str | None = ""
         self.world_config = world_config
         self.rigid_bodies = build_rigid_bodies(world_config.rigid_bodies)
         self.particle_sources = build_particle_sources(world_config.particle_sources)
@@ -250,7 +250,7 @@ class Crate:
                     self._force_ema[name] = 0.8 * self._force_ema.get(name, 0.0) + 0.2 * total / count
         dt_wall = time.perf_counter() - t0
         self._tick_seconds = 0.9 * self._tick_seconds + 0.1 * dt_wall
-        self.set_debug_prints()
+        self._debug_prints = None  # crate.py:129 formats the HUD text every tick; here it is formatted when read
 
     def show_kernel_times(self, on: bool = True) -> None:
         """The reference's HUD splits the frame into its Python phases (crate.py:93-125 under
@@ -450,6 +450,18 @@ class Crate:
             self._engine.set_segments(np.zeros((0, 2, 2)), np.zeros((0, 2, 2)), [])
 
     # ------------------------------------------------------------------ HUD text (crate.py:131-136)
+    @property
+    def debug_prints(self) -> str:
+        """The HUD text the viewer draws every frame (playback.py:81).  Two YAML dumps: formatted on first read after a
+        tick rather than in every tick, which is most of a small scene's tick time."""
+        if self._debug_prints is None:
+            self.set_debug_prints()
+        return self._debug_prints
+
+    @debug_prints.setter
+    def debug_prints(self, text: str) -> None:
+        self._debug_prints = text
+
     def set_debug_prints(self) -> None:
         count = self._count if self._count_known else "?"
         self.debug_prints = f"Tick: {self.tick}\nParticles: {count}\n"

@@ -39,16 +39,18 @@ __device__ __forceinline__ double mt_double(uint32_t a, uint32_t b) {  // NumPy:
   return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
 }
 
-// one thread, state in global memory: the few dozen draws of the particle sources
+// one thread, state staged in LDS: the few dozen draws of the particle sources
 struct RngSerial {
-  RngState* s;
+  uint32_t* mt;  // 624 words in LDS
+  int pos;
+  bool refilled;
   __device__ uint32_t next_u32() {
-    if (s->pos >= kMtN) {
-      uint32_t* mt = s->mt;
+    if (pos >= kMtN) {
       for (int kk = 0; kk < kMtN; ++kk) mt[kk] = mt_twist(mt[kk], mt[(kk + 1) % kMtN], mt[(kk + kMtM) % kMtN]);
-      s->pos = 0;
+      pos = 0;
+      refilled = true;
     }
-    return mt_temper(s->mt[s->pos++]);
+    return mt_temper(mt[pos++]);
   }
   __device__ double next_double() {
     const uint32_t a = next_u32(), b = next_u32();
@@ -71,8 +73,11 @@ struct SourcesK {
 __global__ void k_rng_emit(SourcesK srcs, long long max_particles, RngState* __restrict__ state, int* __restrict__ counters,
                            double* __restrict__ x, double* __restrict__ y, double* __restrict__ vx,
                            double* __restrict__ vy, int* __restrict__ id, int cap) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  RngSerial rng{state};
+  __shared__ uint32_t mt[kMtN];
+  for (int k = threadIdx.x; k < kMtN; k += blockDim.x) mt[k] = state->mt[k];  // one coalesced read instead of a
+  __syncthreads();                                                             // dependent global load per draw
+  if (threadIdx.x != 0) return;
+  RngSerial rng{mt, state->pos, false};
   int stored = counters[C_NS];
   int next_id = counters[C_NEXT_ID];
   for (int k = 0; k < srcs.n; ++k) {
@@ -115,6 +120,9 @@ __global__ void k_rng_emit(SourcesK srcs, long long max_particles, RngState* __r
   }
   counters[C_NS] = stored;
   counters[C_NEXT_ID] = next_id;
+  if (rng.refilled)
+    for (int k = 0; k < kMtN; ++k) state->mt[k] = mt[k];
+  state->pos = rng.pos;
 }
 
 // The collider noise of one tick: 2 * pairs doubles from the stream into eta, in order.  One workgroup: a state

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the counter CSVs of scripts/collect_traffic.sh into profiles/r01_traffic_<N>.json:
+"""Turns the counter CSVs of scripts/collect_traffic.sh into profiles/r02_traffic_<N>.json:
 per kernel, average FETCH_SIZE / WRITE_SIZE per launch in bytes, raw and calibrated."""
 import collections
 import csv
@@ -40,14 +40,18 @@ res = {"particles": n, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in sep
        "note": "the counters sit on the L2's memory side: Infinity Cache hits are included, so at this size "
                "(working set < 256 MiB) this is L2<->fabric traffic, an upper bound of HBM traffic",
        "kernels": {}}
+best = {}  # several instantiations of one kernel run (the bench's primer uses other tile sizes): keep the workload's
 for k in sorted(set(fetch) | set(write)):
     if not k.startswith("sc::"):
         continue
     name = names.get(k, "neighbors_density" if "k_pass_a" in k else "force_integrate" if "k_pass_b" in k else k)
+    if name not in best or fetch.get(k, 0.0) + write.get(k, 0.0) > fetch.get(best[name], 0.0) + write.get(best[name], 0.0):
+        best[name] = k
+for name, k in sorted(best.items()):
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
     res["kernels"][name] = {"fetch_bytes_raw": f, "write_bytes_raw": w, "fetch_bytes": f * kf, "write_bytes": w * kw,
                             "traffic_bytes": f * kf + w * kw, "traffic_bytes_per_particle": (f * kf + w * kw) / n}
-path = f"profiles/r01_traffic_{n}.json"
+path = f"profiles/r02_traffic_{n}.json"
 json.dump(res, open(path, "w"), indent=1)
 print(json.dumps(res["calibration"]))
 for k, v in res["kernels"].items():
