@@ -142,6 +142,25 @@ def fp64_issue(particles_per_gpu: int, kernels: dict):
     return out
 
 
+def regimes(make_sim, settle, per_gpu: int):
+    """The same workload beyond the timed region: it heats up (12 neighbors per particle is far denser than this
+    fluid's equilibrium) and from some tick on piles up in a corner.  One run of 125 ticks,
+    wall time per tick over three windows; the headline `value` is the first, uniform one."""
+    sim = make_sim()
+    out = {}
+    done = 0
+    for name, upto in (("ticks_0_4_warmup", 5), ("ticks_5_24_uniform", 25), ("ticks_25_104", 105), ("ticks_105_124", 125)):
+        t0 = time.perf_counter()
+        sim.run(upto - done)
+        settle(sim)
+        out[name] = {"ms_per_step": round(1000.0 * (time.perf_counter() - t0) / (upto - done), 5)}
+        done = upto
+    total = sum(out[k]["ms_per_step"] * n for k, n in (("ticks_5_24_uniform", 20), ("ticks_25_104", 80)))
+    out["ticks_5_104"] = {"ms_per_step": round(total / 100.0, 5), "particle_steps_per_s": round(per_gpu * 100.0 / (total / 1000.0) / 100.0, 1)}
+    del out["ticks_0_4_warmup"]
+    return out
+
+
 def drop_in_ticks(ticks: int = 300):
     """The path the reference's viewer calls -- `Crate.physics_tick()` once per frame on config/wave_machine.yaml as
     shipped (particle source active, collider noise from NumPy's MT19937 stream) -- timed tick by tick with the
@@ -360,6 +379,7 @@ def main() -> None:
         if device_flags:
             line["device_flags"] = sorted(set(device_flags))
         if world == 1:
+            line["regimes"] = regimes(make_sim, settle, per_gpu)
             line["drop_in_physics_tick"] = drop_in_ticks()
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)

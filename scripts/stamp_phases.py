@@ -30,3 +30,24 @@ for k, label in ((0, "pass A"), (1, "pass B")):
     print(f"{label}: {ok.sum()} waves, median wave life {np.median(life):.0f} ticks; kernel span {(st[:, -1].max() - st[:, 0].min()):.0f} ticks")
     for j, nm in enumerate(names[k][1:]):
         print(f"    {nm:32s} median {np.median(dt[:, j]):8.0f}   mean {dt[:, j].mean():8.0f}   p95 {np.percentile(dt[:, j], 95):8.0f}")
+
+# ---- timeline over the whole chip on the 100 MHz clock (slots 14 / 15): how many workgroups run at a time?
+for k, label, wpb in ((0, "pass A", 4), (1, "pass B", 4)):
+    st = buf[k, :waves, :].astype(np.float64)
+    blocks = waves // wpb
+    start = st[:blocks * wpb, 14].reshape(blocks, wpb).min(axis=1) * 0.01  # us
+    end = st[:blocks * wpb, 15].reshape(blocks, wpb).max(axis=1) * 0.01
+    ok = (start > 0) & (end > 0)
+    start, end = start[ok], end[ok]
+    t0 = start.min()
+    start, end = start - t0, end - t0
+    dur = end - start
+    span = end.max()
+    prof = [int(((start <= f * span) & (end > f * span)).sum()) for f in np.linspace(0.05, 0.95, 10)]
+    print(f"{label}: {len(dur)} workgroups over {span:.1f} us; workgroup duration median {np.median(dur):.1f} p95 {np.percentile(dur, 95):.1f} "
+          f"max {dur.max():.1f} us; first starts spread over {np.percentile(start, 25):.1f} us (25 % started); last start at {start.max():.1f} us")
+    print(f"    workgroups running at 5 %, 15 %, ... 95 % of the span: {prof}  (slots: {256 * (6 if k == 0 else 4)})")
+    late = np.argsort(end)[-5:]
+    print(f"    the five last to finish: started at {np.round(start[late], 1)} ran {np.round(dur[late], 1)} us")
+    ss = np.sort(start)
+    print("    start time of the k-th workgroup (us):", {k: round(float(ss[k - 1]), 2) for k in (64, 256, 512, 768, 1024, 1280, 1536, 2048, 3072, 4096) if k <= len(ss)})
