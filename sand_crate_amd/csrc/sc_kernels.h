@@ -657,7 +657,7 @@ __device__ __forceinline__ void collider_noise(const World& w, uint64_t z, int s
   }
 }
 
-// r = p_i - (p_j + eta) of crate.py:167-171 from the difference (dx, dy) = p_i - p_j.  Nothing here feeds a decision.
+// r = p_i - (p_j + eta) of crate.py:167-171 from the difference (dx, dy) = p_i - p_j.  Float-tolerance math: no decision is taken on it.
 // Counter mode: eta = (hi32 - 2^31) * eta_scale, folded into one convert and one fused multiply-add per
 // component: r = (dx + 2^31 eta_scale) - u32 * eta_scale.
 template <int NOISE>

@@ -81,7 +81,7 @@ __device__ __host__ __forceinline__ int tile_index(const Tile& t, int slot) {  /
 // A neighbor-table entry is a tile slot (>= 0) or, for a tile too large for u16 slots, -(index+1).
 __device__ __host__ __forceinline__ int entry_index(const Tile& t, int e) { return e >= 0 ? tile_index(t, e) : -e - 1; }
 
-// 1/sqrt(s) to about 2 ulp (explicit fma; nothing here feeds a decision).  s = 0 gives NaN downstream, like the reference's 0/0 (crate.py:174).
+// 1/sqrt(s) to about 2 ulp (explicit fma: no decision is taken on it; the forces it enters are float-tolerance math).  s = 0 gives NaN downstream, like the reference's 0/0 (crate.py:174).
 __device__ __forceinline__ double rsqrt_nr(double s) {
   // v_rsq_f64 is good to ~2^-24 (measured 5e-8); one third-order step, y (1 + e/2 + 3e^2/8) with
   // e = 1 - s y^2, brings it to ~2e-16 in five fp64 operations
@@ -333,7 +333,8 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
   SC_STAMP(0, 6);
   // 4. pair math of pass A: populate_colliders (crate.py:161-175), pressures (:261-275), normals (:337-342)
   if (DENS && live) {
-    // nothing here feeds a decision: multiply-adds may fuse (the file is compiled with -ffp-contract=off)
+    // no decision is taken in this block (P, s are float-tolerance outputs): multiply-adds may fuse here although the
+    // file is compiled with -ffp-contract=off
 #pragma clang fp contract(fast)
     // Per pair (crate.py:167-174, :270, :342), arranged for the fewest float64 instructions:
     //   r = p_i - (p_j + eta),  |r|^2 = s2,  1/|r| = rinv,  c = clip(|r| / d, 0, 1)  (|r| >= 0: only the upper clip acts)
@@ -535,7 +536,10 @@ __device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl,
                                                  const int* __restrict__ offById, const double* __restrict__ P,
                                                  const double* __restrict__ sx, const double* __restrict__ sy,
                                                  double& xi, double& yi, double& Pi) {
-  // nothing here feeds a decision directly: multiply-adds may fuse (the file is compiled with -ffp-contract=off)
+  // No decision is taken in this block, so multiply-adds may fuse (the file is compiled with -ffp-contract=off).  The
+  // velocities it produces do feed decisions later -- the sign test of the wall bounce and the orientation tests of the
+  // crossing check -- which therefore see inputs that may differ from NumPy's by an ulp: inside the 1e-5 contract,
+  // not bit-faithful (the reference's own sums over neighbors are order-dependent to the same degree).
 #pragma clang fp contract(fast)
   auto load = [&](int e, XY& pos, XY& nrm, double& pr) {
     if constexpr (LDS) {
