@@ -327,6 +327,13 @@ int build_world(sc_ctx* c, World& w, const sc_params& p, int nseg, const Seg* se
   w.inv_d = 1.0 / w.d;
   w.eta_scale = (w.d * w.level) * (1.0 / 4294967296.0);
   w.eta_half = (w.d * w.level) * 0.5;
+  w.k_ss = w.dt * w.ss;
+  w.k_pp = w.dt * (1 + w.pamp);
+  w.k_0 = -2 * w.tp * w.dt;
+  w.dt_gx = w.dt * w.gx;
+  w.dt_gy = w.dt * w.gy;
+  w.dt_visc = w.dt * w.visc;
+  w.dt_pamp = w.dt * w.pamp;
   w.nseg = nseg;
   w.nbody = nbody;
   std::memcpy(w.seg, seg, sizeof w.seg);

@@ -36,6 +36,9 @@ struct World {
   double inv_d;      // 1/d, for the float-tolerance math only (never for a decision)
   double eta_scale;  // d * collider_noise_level / 2^32, for the counter noise
   double eta_half;   // 2^31 * eta_scale = d * collider_noise_level / 2
+  // products of the coefficients that pass B would otherwise form per workgroup (the same IEEE products, taken on the host)
+  double k_ss, k_pp, k_0;              // dt ss, dt (1 + pamp), -2 tp dt
+  double dt_gx, dt_gy, dt_visc, dt_pamp;
   // decision thresholds derived on the host, see sc_host.cpp: make_world()
   double t_nbr;      // largest s with sqrt(s) <= d          (collision_detector.py:78-79)
   double t_wall;     // largest s with sqrt(s) <= r * 1.2    (crate.py:229)

@@ -43,8 +43,14 @@ __device__ long long g_stamps[2][kStampWaves][kStampSlots];
     const int wv_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                                 \
     if ((threadIdx.x & 63) == 0 && wv_ < kStampWaves) g_stamps[kernel][wv_][slot] = now_;                \
   } while (0)
+#define SC_STAMP_VALUE(kernel, slot, value)                                                             \
+  do {                                                                                                   \
+    const int wv_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                                 \
+    if ((threadIdx.x & 63) == 0 && wv_ < kStampWaves) g_stamps[kernel][wv_][slot] = (value);             \
+  } while (0)
 #else
 #define SC_STAMP(kernel, slot) do { } while (0)
+#define SC_STAMP_VALUE(kernel, slot, value) do { } while (0)
 #endif
 
 // Tile geometry (measured, profiles/README.md): 256 particles per workgroup beat 128 by 2-3 % (less halo per
@@ -474,6 +480,8 @@ __global__ void __launch_bounds__(kTileW)
   // a tile that fits but is much denser than usual (some dense cell plus its sparse surroundings) is better off
   // on the windowed path, which hands long fruitless walks to the whole wave (measured: profiles/README.md)
   const bool in_lds = total <= min(CAP, kDenseTile);
+  SC_STAMP_VALUE(0, 10, total);
+  SC_STAMP_VALUE(0, 11, tile_id);
 
   // 2. stage (x, y) of the three ranges; every load of the tile is in flight before the first LDS write
   if (in_lds) {
@@ -560,7 +568,7 @@ __device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl,
   const double sxi = ms.x, syi = ms.y;
   const int off = (NOISE == SC_NOISE_HOST) ? offById[idi] : 0;
   const uint64_t zbase = noise_base(w.noise_key, idi);
-  const double k_ss = w.dt * w.ss, k_pp = w.dt * (1 + w.pamp), k_0 = -2 * w.tp * w.dt;
+  const double k_ss = w.k_ss, k_pp = w.k_pp, k_0 = w.k_0;
   double tx = 0, ty = 0, mtx = 0, mty = 0;
 #pragma unroll
   for (int s = 0; s < kMaxNbr; ++s) {
@@ -621,25 +629,25 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
 #pragma clang fp contract(fast)
   vxi += ps.tx;  // crate.py:352 and the particle part of :306
   vyi += ps.ty;
-  vxi += w.dt * w.gx;  // crate.py:310
-  vyi += w.dt * w.gy;
+  vxi += w.dt_gx;  // crate.py:310
+  vyi += w.dt_gy;
   double wallx = 0, wally = 0;
   if (ws >= 0) {
     const double* rec = wrec + 5 * (size_t)ws;
     Ux = rec[0]; Uy = rec[1]; Cx = rec[2]; Cy = rec[3]; V = rec[4];
-    const double dpa = w.dt * w.pamp * Pi;  // wall colliders carry pressure 0 and are not normalised (crate.py:286-306)
+    const double dpa = w.dt_pamp * Pi;  // wall colliders carry pressure 0 and are not normalised (crate.py:286-306)
     wallx = dpa * Ux;
     wally = dpa * Uy;
     vxi += wallx;
     vyi += wally;
   }
-  const double dv = w.dt * w.visc;  // crate.py:319-323: sum_j (v0_j - v_i), v_i the current velocity
+  const double dv = w.dt_visc;  // crate.py:319-323: sum_j (v0_j - v_i), v_i the current velocity
   const double visx = dv * (ux - C * vxi), visy = dv * (uy - C * vyi);
   vxi += visx;
   vyi += visy;
   if constexpr (MON) {
     mon[0] = norm2(ps.mtx, ps.mty);
-    mon[1] = norm2(w.dt * w.gx, w.dt * w.gy);
+    mon[1] = norm2(w.dt_gx, w.dt_gy);
     mon[2] = norm2(ps.tx - ps.mtx + wallx, ps.ty - ps.mty + wally);
     mon[3] = norm2(visx, visy);
     mon[4] = mon[5] = 0.0;
@@ -769,6 +777,8 @@ __global__ void __launch_bounds__(kTileW)
     for (int s = 0; s < kMaxNbr; ++s) js[s] = nbr[(size_t)s * cap + ic];
   }
   const bool in_lds = total <= kTileCapB;
+  SC_STAMP_VALUE(1, 10, total);
+  SC_STAMP_VALUE(1, 11, tile_id);
   const bool ghost = w.slab && (cpacked & kGhostBit);
 #if defined(SC_ABL_B_NOPAIRS)
   const int C = 0;
