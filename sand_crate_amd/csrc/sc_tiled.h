@@ -58,6 +58,9 @@ __device__ long long g_stamps[2][kStampWaves][kStampSlots];
 #ifndef SC_SCAN_BATCH
 #define SC_SCAN_BATCH 4
 #endif
+#ifndef SC_COOP
+#define SC_COOP 2
+#endif
 #ifndef SC_CAP_A
 #define SC_CAP_A 1024
 #define SC_CAP_AW 1536
@@ -159,6 +162,10 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       //   by the whole wave, 64 candidates per step, hits ranked by lane = scan order.  Every
       //   particle still sees its candidates in the reference's order, so the lists are the same.
       constexpr int kHalf = CAP / 2, kSerial = 32;
+#ifdef SC_STAMPS
+      long long dbg_rounds = 0, dbg_stagings = 0, dbg_wants = 0, dbg_coop = 0;
+      int dbg_scan = 0;
+#endif
       const double dstop = w.d * (1.0 + 0x1p-20);
       unsigned short* lp = &list[0][t];                  // next free entry of this thread's list (LDS tiles)
       unsigned short* const lend = &list[kMaxNbr][t];
@@ -198,6 +205,9 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
         } else {
           const int lane = t & 63, wave0 = t & ~63;
           int pos = first, left = want ? count : 0;
+#ifdef SC_STAMPS
+          dbg_wants |= (long long)__popcll(__ballot(left > 0)) << (8 * dbg_scan++);
+#endif
           for (;;) {
             // the unfinished position that is furthest behind, block-wide (keys double-buffered by round)
             int key = left > 0 ? pos * step : INT_MAX;
@@ -210,9 +220,15 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
 #pragma unroll
             for (int k = 1; k < kTileW / 64; ++k) k0 = min(k0, wk[k]);
             if (k0 == INT_MAX) break;  // uniform: nobody has candidates left in this range
+#ifdef SC_STAMPS
+            ++dbg_rounds;
+#endif
             const int p0 = k0 * step;
             if ((unsigned)(p0 - rws) >= (unsigned)CAP) {  // not in the resident window: stage the one around it
               rws = step > 0 ? (p0 / kHalf) * kHalf : max(0, (p0 / kHalf - 1) * kHalf);
+#ifdef SC_STAMPS
+              ++dbg_stagings;
+#endif
               constexpr int kPer = CAP / kTileW;
               XY r[kPer];
 #pragma unroll
@@ -230,47 +246,98 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
             }
             const int ws = rws;
             auto inside = [&](int p) { return (unsigned)(p - ws) < (unsigned)CAP; };
-            for (int b = 0; b < kSerial && left > 0 && inside(pos); ++b) {
-              const XY q = txy[pos - ws];
-              const int verdict = window(q.x, xi);
-              bool over = verdict == 0;
-              if (verdict == 2) {
-                const double dx = q.x - xi, dy = q.y - yi;
-                if (dx * dx + dy * dy <= w.t_nbr) {
-                  list[C][t] = (unsigned short)pos;
-                  over = ++C == kMaxNbr;
+            // kWinBatch candidates per iteration, their LDS reads issued together (a dependent read per candidate made
+            // this loop a chain of LDS latencies: in a pile 32 of them per thread and scan); examined one by one, in order
+            constexpr int kWinBatch = 4;
+            for (int b = 0; b < kSerial && left > 0 && inside(pos); b += kWinBatch) {
+              XY q[kWinBatch];
+              bool ok[kWinBatch];
+#pragma unroll
+              for (int k = 0; k < kWinBatch; ++k) {
+                const int pk = pos + k * step;
+                ok[k] = k < left && inside(pk);
+                q[k] = txy[ok[k] ? pk - ws : 0];
+              }
+#pragma unroll
+              for (int k = 0; k < kWinBatch; ++k) {
+                if (ok[k] && left > 0) {  // left = 0: the scan ended at an earlier candidate of the batch
+                  const int verdict = window(q[k].x, xi);
+                  bool over = verdict == 0;
+                  if (verdict == 2) {
+                    const double dx = q[k].x - xi, dy = q[k].y - yi;
+                    if (dx * dx + dy * dy <= w.t_nbr) {
+                      list[C][t] = (unsigned short)pos;
+                      over = ++C == kMaxNbr;
+                    }
+                  }
+                  pos += step;
+                  left = over ? 0 : left - 1;
                 }
               }
-              pos += step;
-              left = over ? 0 : left - 1;
             }
             unsigned long long m = __ballot(left > 0 && inside(pos));
             while (m) {
-              const int owner = __ffsll(m) - 1;
-              const int opos = __shfl(pos, owner, 64), oleft = __shfl(left, owner, 64), oC = __shfl(C, owner, 64);
-              const double oxi = __shfl(xi, owner, 64), oyi = __shfl(yi, owner, 64);
+#ifdef SC_STAMPS
+              ++dbg_coop;
+#endif
+              // the owner's state is read with v_readlane (the owner is wave-uniform): no LDS round trips on the way
+              const int owner = __builtin_amdgcn_readfirstlane(__ffsll(m) - 1);
+              auto of = [&](int v) { return __builtin_amdgcn_readlane(v, owner); };
+              int opos = of(pos), oleft = of(left);
+              const int oC = of(C);
+              const double oxi = __hiloint2double(of(__double2hiint(xi)), of(__double2loint(xi)));
+              const double oyi = __hiloint2double(of(__double2hiint(yi)), of(__double2loint(yi)));
               const int avail = step > 0 ? ws + CAP - opos : opos - ws + 1;  // slots of the window from opos on
-              const int nc = min(min(oleft, avail), 64);
-              const int slot = opos + lane * step;
-              int verdict = 1;
-              bool hit = false;
-              if (lane < nc) {
-                const XY q = txy[slot - ws];
-                verdict = window(q.x, oxi);
-                const double dx = q.x - oxi, dy = q.y - oyi;
-                hit = verdict == 2 && dx * dx + dy * dy <= w.t_nbr;
+              int span = min(oleft, avail);
+              // A long stretch ahead: 64 probes spread over it.  The candidates before the window (verdict 1: the
+              // adjacent-row scans start at the window cell's first particle, in a pile thousands short of x_i - d)
+              // are a prefix of the scan, so everything up to the last leading probe that is still outside is skipped.
+              if (span > 4 * 64) {
+                const int stride = span >> 6;
+                const XY q = txy[opos + lane * stride * step - ws];
+                const unsigned long long out = __ballot(window(q.x, oxi) == 1);
+                const int lead = out == ~0ull ? 64 : __ffsll((long long)~out) - 1;
+                if (lead > 0) {
+                  const int skip = (lead - 1) * stride + 1;
+                  opos += skip * step;
+                  oleft -= skip;
+                  span -= skip;
+                }
               }
-              const unsigned long long stopm = __ballot(verdict == 0);
-              const int nlive = stopm ? __ffsll(stopm) - 1 : nc;  // candidates ahead of the stop
-              const unsigned long long hitm = __ballot(hit && lane < nlive);
+              // the rest of the owner's stretch inside this window, kCoop x 64 candidates per step (their LDS reads
+              // issued together), hits ranked in scan order
+              constexpr int kCoop = SC_COOP;
               const int need = kMaxNbr - oC;
-              const int rank = __popcll(hitm & ((1ull << lane) - 1ull));
-              if (hit && lane < nlive && rank < need) list[oC + rank][wave0 + owner] = (unsigned short)slot;
-              const int nh = min((int)__popcll(hitm), need);
+              int taken = 0, done = 0;
+              bool stopped = false;
+              while (done < span && !stopped) {
+                const int nc = min(span - done, 64 * kCoop);
+                XY q[kCoop];
+#pragma unroll
+                for (int c = 0; c < kCoop; ++c) q[c] = txy[c * 64 + lane < nc ? opos + (done + c * 64 + lane) * step - ws : 0];
+#pragma unroll
+                for (int c = 0; c < kCoop; ++c) {
+                  if (!stopped && c * 64 < nc) {  // wave-uniform
+                    const bool valid = c * 64 + lane < nc;
+                    const int verdict = valid ? window(q[c].x, oxi) : 1;
+                    const double dx = q[c].x - oxi, dy = q[c].y - oyi;
+                    const bool hit = verdict == 2 && dx * dx + dy * dy <= w.t_nbr;
+                    const unsigned long long stopm = __ballot(verdict == 0);
+                    const int nlive = stopm ? __ffsll(stopm) - 1 : 64;  // candidates ahead of the stop
+                    const unsigned long long hitm = __ballot(hit && lane < nlive);
+                    const int rank = taken + __popcll(hitm & ((1ull << lane) - 1ull));
+                    if (hit && lane < nlive && rank < need)
+                      list[oC + rank][wave0 + owner] = (unsigned short)(opos + (done + c * 64 + lane) * step);
+                    taken = min(taken + (int)__popcll(hitm), need);
+                    stopped = stopm != 0 || taken == need;
+                  }
+                }
+                done += nc;
+              }
               if (lane == owner) {
-                C = oC + nh;
-                pos = opos + nc * step;
-                left = (stopm != 0 || nh == need) ? 0 : oleft - nc;
+                C = oC + taken;
+                pos = opos + done * step;
+                left = stopped ? 0 : oleft - done;
               }
               m = __ballot(left > 0 && inside(pos));
             }
@@ -291,6 +358,12 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       scan(live && C < kMaxNbr, tl.n0 + tl.n1 + (em - 1 - tl.a2), em - bm, -1,
            [&](double xj, double xq) { return !(xq <= xj + w.d) ? 0 : (xq >= xj - w.d ? 2 : 1); });
       if constexpr (LDS) C = (int)(lp - &list[0][t]) / (kTileW + 2);
+#ifdef SC_STAMPS
+      SC_STAMP_VALUE(0, 12, dbg_rounds);
+      SC_STAMP_VALUE(0, 13, dbg_stagings);
+      SC_STAMP_VALUE(0, 14, dbg_wants);
+      SC_STAMP_VALUE(0, 15, dbg_coop);
+#endif
     } else if (live) {
       // a tile beyond 65535 particles (a block inside one gigantic bucket) cannot use u16 slots:
       // entries go straight to the table as -(index+1); correctness path only
