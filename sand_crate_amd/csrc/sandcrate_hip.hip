@@ -111,7 +111,6 @@ struct sc_ctx {
   hipEvent_t snap_ready = nullptr, snap_done = nullptr;
   int* colHist = nullptr;      // sc_column_histogram
   int64_t colHistAlloc = 0;
-  int* rankAcc = nullptr;  // per bucket slot: rank inside a big bucket (k_rank_big adds, k_reorder takes and clears)
   // host-mapped progress block written by the GPU, read by the host without synchronisation:
   // [0] big buckets seen by the last finished scan, [1] ticks finished, [2] live particles of that tick,
   // [4 + 4 (tick % kHaloRing) ..]: halo record counts of that tick (sent left / right, received left / right)
@@ -536,8 +535,6 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
   if (e == hipSuccess) e = dalloc(&c->tileBand, n / kTileW + 2);
   if (e == hipSuccess) e = hipMemsetAsync(c->tileBand, 0, (n / kTileW + 2) * sizeof(int), c->stream);
   if (e == hipSuccess) e = dalloc(&c->bigList, (size_t)kMaxBig);
-  if (e == hipSuccess) e = dalloc(&c->rankAcc, n);
-  if (e == hipSuccess) e = hipMemsetAsync(c->rankAcc, 0, n * sizeof(int), c->stream);
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->bigHintHost, kProgressInts * sizeof(int), hipHostMallocMapped);
   if (e == hipSuccess) {
     for (int k = 0; k < kProgressInts; ++k) c->bigHintHost[k] = 0;
@@ -576,7 +573,7 @@ int sc_destroy(sc_ctx* c) {
   }
   if (c->ev_band) (void)hipEventDestroy(c->ev_band);
   if (c->ev_xchg) (void)hipEventDestroy(c->ev_xchg);
-  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->tileBand, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->rankAcc, c->wrec[0], c->wrec[1],
+  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->tileBand, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->wrec[0], c->wrec[1],
                   c->nbr, c->nbr16, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
                   c->stage_xy, c->stage_vxy, c->stage_ids, c->owned_out, c->colHist, c->rng, c->monitor,
                   c->snap_d[0], c->snap_d[1], c->snap_d[2], c->snap_d[3], c->snap_id_d, c->snap_rng_d};
@@ -742,15 +739,15 @@ int sc_step_begin(sc_ctx* c) {
   // hint in host-mapped memory): rank this tick's big buckets over the whole GPU first
   if (c->force_rank_big || *(volatile int*)c->bigHintHost > 0) {
     Bracket br(c, K_SCAN);
-    hipLaunchKernelGGL(k_rank_big, dim3(4 * c->num_cus), dim3(kRankTile), 0, c->stream, c->counters, c->bigList,
-                       Buckets{c->cellStart, c->blockOff}, c->keyX, c->keyId, c->rankAcc, c->sortedStamp, stamp);
+    hipLaunchKernelGGL(k_sort_big, dim3(4 * c->num_cus), dim3(kSortBlock), 0, c->stream, c->counters, c->bigList,
+                       Buckets{c->cellStart, c->blockOff}, c->keyX, c->keyId, c->perm, c->sortedStamp, stamp);
   }
   {
     Bracket br(c, K_REORDER);
     hipLaunchKernelGGL(k_reorder, dim3((int)std::max<int64_t>(1, (launch_bound(c) + kReorderBlock - 1) / kReorderBlock)),
                        dim3(kReorderBlock), 0, c->stream, c->counters, c->perm, c->keyX, c->keyId,
                        c->cellS, Buckets{c->cellStart, c->blockOff}, c->wslotS, c->y[0], c->vx[0], c->vy[0], c->x[1], c->y[1], c->vx[1],
-                       c->vy[1], c->id[1], c->cellT, c->wslotT, c->sortedStamp, stamp, c->rankAcc, w.ncols, c->tileBounds);
+                       c->vy[1], c->id[1], c->cellT, c->wslotT, c->sortedStamp, stamp, w.ncols, c->tileBounds);
   }
   // SC_NOISE_HOST (and the stand-alone search) stop after the lists: the host's rand block can only be
   // indexed once every count is known.  Otherwise the search and pass A are one launch.

@@ -248,7 +248,9 @@ __global__ void __launch_bounds__(kBlock) k_scan_fix(int* __restrict__ out, int 
 // 2048-cell block (cellStart) and the start of the block (blockOff) -- so that no second pass over
 // the cells is needed: every workgroup scans its block, and the last one to finish (ticket) scans
 // the block totals.  Readers add the two (struct Buckets).  Saves a ~5 us launch per tick.
-constexpr int kSortThreshold = 96;  // buckets above this many particles are listed for k_rank_big
+constexpr int kScrambledHeads = 28;  // a wave with more runs of equal cells than this groups its lanes by cell (k_scatter)
+constexpr int kMatchRounds = 12;
+constexpr int kSortThreshold = 96;  // buckets above this many particles are listed for k_sort_big
 constexpr int kMaxBig = 4096;       // room in the list of big buckets
 constexpr int kScanShift = 11;
 static_assert((1 << kScanShift) == kScanPerBlock, "block offset lookup assumes 2048 cells per scan block");
@@ -330,42 +332,41 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
     counters[C_NT] = carry;  // live particles = entries of the sorted arrays
     counters[C_TICKET] = 0;
     // a hint for the host, in host-mapped memory: were there big buckets?  It is read without any
-    // synchronisation when the NEXT tick is enqueued and only decides whether k_rank_big is launched.
+    // synchronisation when the NEXT tick is enqueued and only decides whether k_sort_big is launched.
     bigHint[0] = __hip_atomic_load(&counters[C_NBIG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// K3b  ranks inside big buckets.  Ranking a bucket of k particles costs k^2 compares; done inside K4
-// by the few workgroups that hold the bucket, a pile of thousands of particles in one cell (stopped
-// in a corner by the continuous-collision fix, many with exactly equal x) takes hundreds of
-// microseconds.  Here the k^2 compares of every bucket the scan listed are cut into tasks of
-// kRankTile x kRankTile and dealt over the whole GPU; a task counts, for its kRankTile particles, the
-// keys of its chunk that are smaller by (x, id) and adds that to the particle's slot in rankAcc.
-// The bucket is stamped; K4 takes the rank from rankAcc (and clears it).  Launched only when the
-// previous tick saw big buckets; a bucket that is not stamped is ranked inside K4 as before.
+// K3b  big buckets are SORTED before K4 ranks them.  Ranking a bucket of k particles by counting costs k^2
+// compares; a pile of thousands of particles in one cell (stopped against a wall by the continuous-collision fix,
+// many with exactly equal x) made that the longest kernel of the tick -- in the contract workload's pile-up
+// regime half of all particles sit in such buckets.  Here every bucket the scan listed is cut into chunks of
+// kSortChunk slots and every chunk is sorted by (x, id) in LDS (bitonic network, one workgroup per chunk, the
+// storage index travels along) and written back in place: a bucket segment is in arrival order anyway, any
+// permutation of it is as good.  The bucket is stamped; K4 then takes a particle's rank as its position inside
+// its chunk plus, for buckets of several chunks, a binary search in each of the other chunks.
+// Launched only when the previous tick saw big buckets; a bucket that is not stamped is ranked inside K4 by counting.
 // ------------------------------------------------------------------------------------------
-constexpr int kRankTile = 256;
+constexpr int kSortBlock = 256;
+constexpr int kSortChunk = 2048;       // 32 KB of LDS for (x, id, storage index)
 constexpr int kRankMaxBuckets = 1024;  // big buckets handled per tick (more: the rest is ranked in K4)
 
-struct RankKey {
-  double x;
-  int id, pad;
-};
+__device__ __forceinline__ bool key_less(double xa, int ia, double xb, int ib) { return xa < xb || (xa == xb && ia < ib); }
 
-__global__ void __launch_bounds__(kRankTile)
-    k_rank_big(const int* __restrict__ counters, const int* __restrict__ bigList, Buckets bk,
-               const double* __restrict__ keyX, const int* __restrict__ keyId, int* __restrict__ rankAcc,
-               int* __restrict__ sortedStamp, int stamp) {
+__global__ void __launch_bounds__(kSortBlock)
+    k_sort_big(const int* __restrict__ counters, const int* __restrict__ bigList, Buckets bk, double* __restrict__ keyX,
+               int* __restrict__ keyId, int* __restrict__ perm, int* __restrict__ sortedStamp, int stamp) {
   __shared__ int pre[kRankMaxBuckets + 1];  // tasks before bucket q
   __shared__ int bstart[kRankMaxBuckets], blen[kRankMaxBuckets];
-  __shared__ int waveTot[kRankTile / 64];
-  __shared__ RankKey chunk[kRankTile];
+  __shared__ int waveTot[kSortBlock / 64];
+  __shared__ double kx[kSortChunk];
+  __shared__ int kid[kSortChunk], kpm[kSortChunk];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nbig = min(__hip_atomic_load(&counters[C_NBIG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), kRankMaxBuckets);
   if (nbig == 0) return;
   // every workgroup derives the same task table from the same list
-  constexpr int kPer = kRankMaxBuckets / kRankTile;
+  constexpr int kPer = kRankMaxBuckets / kSortBlock;
   int tasks[kPer], sum = 0;
 #pragma unroll
   for (int k = 0; k < kPer; ++k) {
@@ -374,10 +375,9 @@ __global__ void __launch_bounds__(kRankTile)
     if (q < nbig) {
       const int c = bigList[q];
       const int b = bk(c), len = bk(c + 1) - b;
-      const int tiles = (len + kRankTile - 1) / kRankTile;
       bstart[q] = b;
       blen[q] = len;
-      t = tiles * tiles;
+      t = (len + kSortChunk - 1) / kSortChunk;
     }
     tasks[k] = sum;
     sum += t;
@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(kRankTile)
   if (lane == 63) waveTot[wv] = incl;
   __syncthreads();
   int wbase = 0, total = 0;
-  for (int k = 0; k < kRankTile / 64; ++k) {
+  for (int k = 0; k < kSortBlock / 64; ++k) {
     if (k < wv) wbase += waveTot[k];
     total += waveTot[k];
   }
@@ -407,26 +407,43 @@ __global__ void __launch_bounds__(kRankTile)
       if (pre[mid] <= task) lo = mid; else hi = mid;
     }
     const int q = lo, local = task - pre[q];
-    const int b = bstart[q], len = blen[q];
-    const int tiles = (len + kRankTile - 1) / kRankTile;
-    const int ti = local / tiles, tj = local - ti * tiles;
-    const int j = tj * kRankTile + tid, i = ti * kRankTile + tid;
-    __syncthreads();
-    chunk[tid] = j < len ? RankKey{keyX[b + j], keyId[b + j], 0} : RankKey{__builtin_huge_val(), 0x7FFFFFFF, 0};
-    double xi = 0;
-    int idi = 0;
-    if (i < len) {
-      xi = keyX[b + i];
-      idi = keyId[b + i];
+    const int b = bstart[q] + local * kSortChunk, len = min(kSortChunk, blen[q] - local * kSortChunk);
+    int n = 64;  // the network's size: the power of two that holds the chunk
+    while (n < len) n <<= 1;
+    __syncthreads();  // the previous task's write-back has read the arrays
+    for (int e = tid; e < n; e += kSortBlock) {
+      const bool in = e < len;
+      kx[e] = in ? keyX[b + e] : __builtin_huge_val();  // padding sorts behind every key (ids are below INT_MAX)
+      kid[e] = in ? keyId[b + e] : 0x7FFFFFFF;
+      kpm[e] = in ? perm[b + e] : 0;
     }
     __syncthreads();
-    int r = 0;
-#pragma unroll 8
-    for (int k = 0; k < kRankTile; ++k) {
-      const RankKey o = chunk[k];
-      r += (o.x < xi) || (o.x == xi && o.id < idi);
+    for (int k = 2; k <= n; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int e = tid; e < (n >> 1); e += kSortBlock) {
+          const int i = ((e & ~(j - 1)) << 1) | (e & (j - 1));  // e with a zero bit inserted at j's position
+          const int p = i | j;
+          const double xa = kx[i], xb = kx[p];
+          const int ia = kid[i], ib = kid[p];
+          const bool up = (i & k) == 0;  // this pair sorts ascending
+          if (key_less(xb, ib, xa, ia) == up) {
+            kx[i] = xb;
+            kx[p] = xa;
+            kid[i] = ib;
+            kid[p] = ia;
+            const int pa = kpm[i];
+            kpm[i] = kpm[p];
+            kpm[p] = pa;
+          }
+        }
+        __syncthreads();
+      }
     }
-    if (i < len && r) atomicAdd(&rankAcc[b + i], r);
+    for (int e = tid; e < len; e += kSortBlock) {
+      keyX[b + e] = kx[e];
+      keyId[b + e] = kid[e];
+      perm[b + e] = kpm[e];
+    }
     if (local == 0 && tid == 0) sortedStamp[bigList[q]] = stamp;
   }
 }
@@ -463,12 +480,40 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ coun
   if (i >= counters[C_NS]) c = -1;
   if (c >= 0) c &= kCellMask;
   const int lane = threadIdx.x & 63;
+  // Storage order is the previous tick's sorted order, so the lanes of a run share a cell -- as long as particles
+  // stay near their cells.  In a pile-up they do not (the contract workload's particles cross more than a cell per
+  // tick by then): runs shrink to one or two lanes and a cell of thousands takes thousands of returning atomics on
+  // one address.  A wave that finds itself that scrambled (many run heads) groups its lanes by cell whatever their
+  // order, one atomic per cell, for up to kMatchRounds cells; what is left goes by runs as usual.
+  int pos = -1;
   LaneRun run = lane_run(c >= 0 ? c : -1 - lane);
+  const bool scrambled = __popcll(__ballot(run.is_head && c >= 0)) > kScrambledHeads;  // wave-uniform
+  if (scrambled) {
+    unsigned long long todo = __ballot(c >= 0);
+    int my_leader = -1, my_off = 0, my_len = 0;
+    for (int it = 0; it < kMatchRounds && todo; ++it) {
+      const int leader = __builtin_amdgcn_readfirstlane(__ffsll(todo) - 1);
+      const int kc = __builtin_amdgcn_readlane(c, leader);
+      const unsigned long long grp = __ballot(c == kc);
+      if (c == kc) {
+        my_leader = leader;
+        my_off = (int)__popcll(grp & ((1ull << lane) - 1ull));
+        my_len = (int)__popcll(grp);
+      }
+      todo &= ~grp;
+    }
+    int base = 0;  // the groups' atomics leave together
+    if (my_leader == lane) base = bk(c) + atomicSub(&cellCount[c], my_len) - my_len;
+    base = __shfl(base, my_leader >= 0 ? my_leader : lane, 64);
+    if (my_leader >= 0) pos = base + my_off;
+  }
+  const bool rest = c >= 0 && pos < 0;
+  if (scrambled) run = lane_run(rest ? c : -1 - lane);
   int base = 0;
-  if (run.is_head && c >= 0) base = bk(c) + atomicSub(&cellCount[c], run.len) - run.len;
+  if (run.is_head && rest) base = bk(c) + atomicSub(&cellCount[c], run.len) - run.len;
   base = __shfl(base, run.head, 64);
   if (c < 0) return;
-  int pos = base + (lane - run.head);
+  if (rest) pos = base + (lane - run.head);
   perm[pos] = i;
   keyX[pos] = xi;
   keyId[pos] = idi;
@@ -492,8 +537,8 @@ __global__ void __launch_bounds__(kReorderBlock)
               const int* __restrict__ wslotS, const double* __restrict__ yS, const double* __restrict__ vxS,
               const double* __restrict__ vyS, double* __restrict__ xT, double* __restrict__ yT,
               double* __restrict__ vxT, double* __restrict__ vyT, int* __restrict__ idT, int* __restrict__ cellT,
-              int* __restrict__ wslotT, const int* __restrict__ sortedStamp, int stamp, int* __restrict__ rankAcc,
-              int ncols, int* __restrict__ tileBounds) {
+              int* __restrict__ wslotT, const int* __restrict__ sortedStamp, int stamp, int ncols,
+              int* __restrict__ tileBounds) {
   __shared__ double ckx[kRankChunk];
   __shared__ int cki[kRankChunk];
   __shared__ int pick;
@@ -516,11 +561,22 @@ __global__ void __launch_bounds__(kReorderBlock)
     e = bk(c + 1);
   }
   int rank = 0;
-  // a bucket k_rank_big has ranked this tick: take the rank and leave the accumulator clean
+  // a bucket k_sort_big has sorted this tick, chunk by chunk: the rank is the position inside the particle's chunk
+  // plus the keys below (x, id) in each of the bucket's other chunks
   const bool presorted = live && (e - b) > kSortThreshold && sortedStamp[c] == stamp;
   if (presorted) {
-    rank = rankAcc[s];
-    rankAcc[s] = 0;
+    const int mine = (s - b) / kSortChunk;
+    rank = (s - b) - mine * kSortChunk;
+    for (int cb = b, r = 0; cb < e; cb += kSortChunk, ++r) {
+      if (r == mine) continue;
+      int lo = cb, hi = min(cb + kSortChunk, e);  // first key of the chunk that is not below (x, id)
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const double xm = keyX[mid];
+        if (xm < xi || (xm == xi && keyId[mid] < idi)) lo = mid + 1; else hi = mid;
+      }
+      rank += lo - cb;
+    }
   }
   const bool big = live && !presorted && (e - b) > kBigBucket;
   if (live && !big && !presorted) {
