@@ -81,7 +81,8 @@ struct sc_ctx {
   int *cellS = nullptr, *wslotS = nullptr, *cellT = nullptr, *wslotT = nullptr, *perm = nullptr;
   double* keyX = nullptr;
   int* keyId = nullptr;
-  int* tileBounds = nullptr;
+  int* tileBounds = nullptr;   // per block of kTileW sorted particles: its three candidate ranges (k_reorder)
+  int* tileBoundsT = nullptr;  // ... the three ranges its neighbor-table slots refer to (the search; sc_tiled.h)
   int* tileBand = nullptr;  // per block of pass A / B: holds a particle that may be packed into a halo message
   // halo overlap (sc_set_halo_overlap): the exchange runs on the side stream between the two launches of pass B
   bool overlap = false, band_pending = false;
@@ -447,7 +448,7 @@ template <int NOISE, bool ENUM, bool DENS, int CAP>
 void launch_pass_a_cap(sc_ctx* c) {
   hipLaunchKernelGGL((k_pass_a<NOISE, ENUM, DENS, CAP>), dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters,
                      c->x[1], c->y[1], c->id[1], c->cellT, Buckets{c->cellStart, c->blockOff}, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta, c->offById,
-                     c->P, c->sx, c->sy, c->tileBounds, c->tileBand);
+                     c->P, c->sx, c->sy, ENUM ? c->tileBounds : c->tileBoundsT, c->tileBand, c->tileBoundsT);
 }
 
 template <int NOISE, bool ENUM, bool DENS>
@@ -472,7 +473,7 @@ void launch_pass_b(sc_ctx* c, const WallInputs& wn, int part = 0) {
   hipLaunchKernelGGL((k_pass_b<NOISE, FUSED, MON>), dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters, c->x[1],
                      c->y[1], c->vx[1], c->vy[1], c->id[1], c->wslotT, c->cellT, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta,
                      c->offById, c->P, c->sx, c->sy, c->wrec[cur], c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0],
-                     c->tileBounds, c->bigHintDev, wn, c->cellS, c->wslotS, c->cellCount, c->wrec[nxt], c->haloL, c->haloR,
+                     c->tileBoundsT, c->bigHintDev, wn, c->cellS, c->wslotS, c->cellCount, c->wrec[nxt], c->haloL, c->haloR,
                      c->haloCap, c->monitor, c->tileBand, part);
 }
 
@@ -532,6 +533,7 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
   if (e == hipSuccess) e = dalloc(&c->keyX, n);
   if (e == hipSuccess) e = dalloc(&c->keyId, n);
   if (e == hipSuccess) e = dalloc(&c->tileBounds, 6 * (n / kTileW + 2));
+  if (e == hipSuccess) e = dalloc(&c->tileBoundsT, 6 * (n / kTileW + 2));
   if (e == hipSuccess) e = dalloc(&c->tileBand, n / kTileW + 2);
   if (e == hipSuccess) e = hipMemsetAsync(c->tileBand, 0, (n / kTileW + 2) * sizeof(int), c->stream);
   if (e == hipSuccess) e = dalloc(&c->bigList, (size_t)kMaxBig);
@@ -573,7 +575,7 @@ int sc_destroy(sc_ctx* c) {
   }
   if (c->ev_band) (void)hipEventDestroy(c->ev_band);
   if (c->ev_xchg) (void)hipEventDestroy(c->ev_xchg);
-  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->tileBand, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->wrec[0], c->wrec[1],
+  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->tileBoundsT, c->tileBand, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->wrec[0], c->wrec[1],
                   c->nbr, c->nbr16, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
                   c->stage_xy, c->stage_vxy, c->stage_ids, c->owned_out, c->colHist, c->rng, c->monitor,
                   c->snap_d[0], c->snap_d[1], c->snap_d[2], c->snap_d[3], c->snap_id_d, c->snap_rng_d};
@@ -1033,7 +1035,7 @@ int sc_download_neighbors(sc_ctx* c, int64_t* ids, int32_t* counts, int64_t* nei
   std::vector<unsigned short> slot16(n);
   const int64_t nblocks = (n + kTileW - 1) / kTileW;
   std::vector<int> tb(6 * std::max<int64_t>(nblocks, 1));
-  if ((rc = fetch(c, tb.data(), c->tileBounds, 6 * nblocks * sizeof(int)))) return rc;
+  if ((rc = fetch(c, tb.data(), c->tileBoundsT, 6 * nblocks * sizeof(int)))) return rc;
   if ((rc = fetch(c, id.data(), c->id[1], n * sizeof(int))) || (rc = fetch(c, cnt.data(), c->cnt, n)) ||
       (rc = fetch(c, hx.data(), c->x[1], n * sizeof(double))) || (rc = fetch(c, hy.data(), c->y[1], n * sizeof(double))))
     return rc;

@@ -156,9 +156,29 @@ __device__ __forceinline__ int wall_and_cell(const W& w, double& px, double& py,
 
 // Bucket count of a wave's particles: one atomic per run of equal cells (lanes without a cell get
 // distinct negative keys).  Every lane of the wave must call it.
+// A wave whose particles no longer sit in their old cells (many short runs: a pile-up, where a cell of thousands
+// would otherwise take thousands of atomics on one address -- they serialise at ~15 ns each and the kernel ends
+// when the last one has landed) first groups its lanes by cell whatever their order, one atomic per cell, for up
+// to kMatchRounds cells.
+constexpr int kScrambledHeads = 28;  // more runs of equal cells than this in a wave: group the lanes by cell
+constexpr int kMatchRounds = 12;
 __device__ __forceinline__ void count_cells(int c, int* __restrict__ cellCount) {
-  LaneRun run = lane_run(c >= 0 ? (c & kCellMask) : -1 - (int)(threadIdx.x & 63));
-  if (run.is_head && c >= 0) atomicAdd(&cellCount[c & kCellMask], run.len);
+  const int lane = threadIdx.x & 63;
+  int key = c >= 0 ? (c & kCellMask) : -1 - lane;
+  LaneRun run = lane_run(key);
+  if (__popcll(__ballot(run.is_head && c >= 0)) > kScrambledHeads) {  // wave-uniform
+    unsigned long long todo = __ballot(c >= 0);
+    for (int it = 0; it < kMatchRounds && todo; ++it) {
+      const int leader = __builtin_amdgcn_readfirstlane(__ffsll(todo) - 1);
+      const int kc = __builtin_amdgcn_readlane(key, leader);
+      const unsigned long long grp = __ballot(key == kc);
+      if (lane == leader) atomicAdd(&cellCount[kc], (int)__popcll(grp));
+      if (key == kc) key = -1 - lane;  // counted
+      todo &= ~grp;
+    }
+    run = lane_run(key);
+  }
+  if (run.is_head && key >= 0) atomicAdd(&cellCount[key], run.len);
 }
 
 __global__ void __launch_bounds__(kBlock) k_wall_bin(World w, int* __restrict__ counters, double* __restrict__ x,
@@ -248,8 +268,6 @@ __global__ void __launch_bounds__(kBlock) k_scan_fix(int* __restrict__ out, int 
 // 2048-cell block (cellStart) and the start of the block (blockOff) -- so that no second pass over
 // the cells is needed: every workgroup scans its block, and the last one to finish (ticket) scans
 // the block totals.  Readers add the two (struct Buckets).  Saves a ~5 us launch per tick.
-constexpr int kScrambledHeads = 28;  // a wave with more runs of equal cells than this groups its lanes by cell (k_scatter)
-constexpr int kMatchRounds = 12;
 constexpr int kSortThreshold = 96;  // buckets above this many particles are listed for k_sort_big
 constexpr int kMaxBig = 4096;       // room in the list of big buckets
 constexpr int kScanShift = 11;

@@ -124,7 +124,8 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
                                             unsigned short* __restrict__ nbr16,
                                             unsigned char* __restrict__ cnt, const int cap,
                                             const double* __restrict__ eta, const int* __restrict__ offById,
-                                            double* __restrict__ P, double* __restrict__ sx, double* __restrict__ sy) {
+                                            double* __restrict__ P, double* __restrict__ sx, double* __restrict__ sy,
+                                            const int tile_id, int* __restrict__ tileBoundsT) {
   auto load_xy = [&](int slot) -> XY {
     if constexpr (LDS) {
       return txy[slot];
@@ -466,11 +467,85 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
   }
 
   SC_STAMP(0, 7);
-  // 5. lists out, slot-major: for a fixed slot consecutive threads write consecutive words
-  if (ENUM && live) {
-    if (slots_fit)
-      for (int s = 0; s < C; ++s) nbr16[(size_t)s * cap + i] = list[s][t];
-    cnt[i] = (unsigned char)C;
+  // 5. lists out, slot-major: for a fixed slot consecutive threads write consecutive words.
+  // The table's slots refer to the ranges published in tileBoundsT -- for the usual tile the candidate ranges.  A
+  // tile whose candidate ranges exceed pass B's LDS budget (a block in or beside a pile: thousands of candidates,
+  // of which the lists name a few hundred) publishes the ranges its lists actually reach instead -- per range from
+  // the lowest to the highest slot named, the block's own particles included -- and renumbers its entries, so that
+  // pass B stages these tiles in LDS like any other instead of gathering every neighbor from global memory.
+  if (ENUM) {
+    int nb0 = tl.a0, nb1 = tl.a0 + tl.n0, nb2 = tl.a1, nb3 = tl.a1 + tl.n1, nb4 = tl.a2, nb5 = tl.a2 + tl.n2;
+    const int r1 = tl.n0, r2 = tl.n0 + tl.n1;  // first slot of the next rows' / previous rows' range
+    int sub0 = 0, sub1 = 0, sub2 = 0;          // what renumbering takes off an entry of each range
+    const bool trim = slots_fit && total > kTileCapB;  // uniform over the workgroup
+    if (trim) {
+      int lo0 = live ? self : INT_MAX, hi0 = live ? self : -1, lo1 = INT_MAX, hi1 = -1, lo2 = INT_MAX, hi2 = -1;
+      if (live)
+        for (int s = 0; s < C; ++s) {
+          const int e = list[s][t];
+          if (e < r1) {
+            lo0 = min(lo0, e);
+            hi0 = max(hi0, e);
+          } else if (e < r2) {
+            lo1 = min(lo1, e);
+            hi1 = max(hi1, e);
+          } else {
+            lo2 = min(lo2, e);
+            hi2 = max(hi2, e);
+          }
+        }
+      for (int o = 32; o > 0; o >>= 1) {
+        lo0 = min(lo0, __shfl_xor(lo0, o, 64));
+        hi0 = max(hi0, __shfl_xor(hi0, o, 64));
+        lo1 = min(lo1, __shfl_xor(lo1, o, 64));
+        hi1 = max(hi1, __shfl_xor(hi1, o, 64));
+        lo2 = min(lo2, __shfl_xor(lo2, o, 64));
+        hi2 = max(hi2, __shfl_xor(hi2, o, 64));
+      }
+      __syncthreads();  // the scans are done with wkey
+      if ((t & 63) == 0) {
+        int* wk = wkey + 6 * (t >> 6);
+        wk[0] = lo0; wk[1] = hi0; wk[2] = lo1; wk[3] = hi1; wk[4] = lo2; wk[5] = hi2;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < kTileW / 64; ++k) {
+        const int* wk = wkey + 6 * k;
+        lo0 = min(lo0, wk[0]); hi0 = max(hi0, wk[1]);
+        lo1 = min(lo1, wk[2]); hi1 = max(hi1, wk[3]);
+        lo2 = min(lo2, wk[4]); hi2 = max(hi2, wk[5]);
+      }
+      const int m0 = hi0 - lo0 + 1;  // never empty: the block's own particles
+      const int m1 = hi1 >= lo1 ? hi1 - lo1 + 1 : 0, m2 = hi2 >= lo2 ? hi2 - lo2 + 1 : 0;
+      if (m1 == 0) lo1 = r1;
+      if (m2 == 0) lo2 = r2;
+      nb0 = tl.a0 + lo0;
+      nb1 = nb0 + m0;
+      nb2 = tl.a1 + (lo1 - r1);
+      nb3 = nb2 + m1;
+      nb4 = tl.a2 + (lo2 - r2);
+      nb5 = nb4 + m2;
+      sub0 = lo0;
+      sub1 = lo1 - m0;
+      sub2 = lo2 - m0 - m1;
+    }
+    if (t == 0) {
+      int* tbT = tileBoundsT + 6 * tile_id;
+      tbT[0] = nb0; tbT[1] = nb1; tbT[2] = nb2; tbT[3] = nb3; tbT[4] = nb4; tbT[5] = nb5;
+    }
+    if (live) {
+      if (slots_fit) {
+        if (trim) {
+          for (int s = 0; s < C; ++s) {
+            const int e = list[s][t];
+            nbr16[(size_t)s * cap + i] = (unsigned short)(e - (e < r1 ? sub0 : e < r2 ? sub1 : sub2));
+          }
+        } else {
+          for (int s = 0; s < C; ++s) nbr16[(size_t)s * cap + i] = list[s][t];
+        }
+      }
+      cnt[i] = (unsigned char)C;
+    }
   }
   SC_STAMP(0, 8);
 }
@@ -493,12 +568,13 @@ __global__ void __launch_bounds__(kTileW)
              const int* __restrict__ id, const int* __restrict__ cell, Buckets bk,
              int* __restrict__ nbr, unsigned short* __restrict__ nbr16, unsigned char* __restrict__ cnt, int cap,
              const double* __restrict__ eta, const int* __restrict__ offById, double* __restrict__ P, double* __restrict__ sx,
-             double* __restrict__ sy, const int* __restrict__ tileBounds, int* __restrict__ tileBand) {
+             double* __restrict__ sy, const int* __restrict__ tileBounds, int* __restrict__ tileBand,
+             int* __restrict__ tileBoundsT) {
   constexpr int kPad = SC_SCAN_BATCH - 1;  // a batched scan may read this far past either end of the tile
   __shared__ XY txy_padded[CAP + 2 * kPad];
   XY* const txy = txy_padded + kPad;
   __shared__ unsigned short list[kMaxNbr][kTileW + 2];  // tile slots of the neighbors, [slot][thread]
-  __shared__ int wkey[2 * (kTileW / 64)];
+  __shared__ int wkey[6 * (kTileW / 64)];  // the windowed scans' round keys (2 per wave); the lists' reach per range (6 per wave)
 
   const int t = threadIdx.x;
   const int tile_id = tile_of_block();
@@ -580,10 +656,10 @@ __global__ void __launch_bounds__(kTileW)
 
   if (in_lds)
     pass_a_body<NOISE, ENUM, DENS, true, CAP>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr, nbr16, cnt,
-                                         cap, eta, offById, P, sx, sy);
+                                         cap, eta, offById, P, sx, sy, tile_id, tileBoundsT);
   else
     pass_a_body<NOISE, ENUM, DENS, false, CAP>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr,
-                                          nbr16, cnt, cap, eta, offById, P, sx, sy);
+                                          nbr16, cnt, cap, eta, offById, P, sx, sy, tile_id, tileBoundsT);
 }
 
 // ------------------------------------------------------------------------------------------
