@@ -144,12 +144,14 @@ def fp64_issue(particles_per_gpu: int, kernels: dict):
 
 def regimes(make_sim, settle, per_gpu: int):
     """The same workload beyond the timed region: it heats up (12 neighbors per particle is far denser than this
-    fluid's equilibrium) and from some tick on piles up in a corner.  One run of 125 ticks,
-    wall time per tick over three windows; the headline `value` is the first, uniform one."""
+    fluid's equilibrium) and from some tick on (about 150 at 1,048,576 particles) half of the particles sit in cells
+    of thousands along the walls (DESIGN.md section 8).  One run of 475 ticks, wall time per tick over five windows;
+    the headline `value` is the first, uniform one."""
     sim = make_sim()
     out = {}
     done = 0
-    for name, upto in (("ticks_0_4_warmup", 5), ("ticks_5_24_uniform", 25), ("ticks_25_104", 105), ("ticks_105_124", 125)):
+    for name, upto in (("ticks_0_4_warmup", 5), ("ticks_5_24_uniform", 25), ("ticks_25_104", 105), ("ticks_105_124", 125),
+                       ("ticks_125_424", 425), ("ticks_425_474_pile_up", 475)):
         t0 = time.perf_counter()
         sim.run(upto - done)
         settle(sim)

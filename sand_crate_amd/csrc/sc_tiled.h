@@ -348,10 +348,19 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       // same strip, after i: x_j <= x_i + d                                  (:106-109)
       scan(live, self + 1, e0 - (i + 1), 1, [&](double xj, double xq) { return xj > xq + w.d ? 0 : 2; });
       SC_STAMP(0, 3);
+#ifdef SC_STAMPS
+      int dbg_c1 = C;
+      for (int o = 32; o > 0; o >>= 1) dbg_c1 += __shfl_xor(dbg_c1, o, 64);
+#endif
       // next strip: x_i - d <= x_j <= x_i + d                                (:112-119)
       scan(live && C < kMaxNbr, tl.n0 + (b1 - tl.a1), e1 - b1, 1,
            [&](double xj, double xq) { return xj > xq + w.d ? 0 : (xj >= xq - w.d ? 2 : 1); });
       SC_STAMP(0, 4);
+#ifdef SC_STAMPS
+      int dbg_c2 = C;
+      for (int o = 32; o > 0; o >>= 1) dbg_c2 += __shfl_xor(dbg_c2, o, 64);
+      SC_STAMP_VALUE(0, 9, (long long)dbg_c1 | ((long long)dbg_c2 << 32));
+#endif
       // reverse edges (:85-88): i is a forward candidate of j, same strip
       scan(live && C < kMaxNbr, self - 1, i - b0, -1, [&](double xj, double xq) { return !(xq <= xj + w.d) ? 0 : 2; });
       SC_STAMP(0, 5);
@@ -657,9 +666,30 @@ __global__ void __launch_bounds__(kTileW)
   if (in_lds)
     pass_a_body<NOISE, ENUM, DENS, true, CAP>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr, nbr16, cnt,
                                          cap, eta, offById, P, sx, sy, tile_id, tileBoundsT);
-  else
-    pass_a_body<NOISE, ENUM, DENS, false, CAP>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr,
+  else {
+    // Beyond the LDS budget the threads take the block's particles in stride (thread t: particle (t mod 64) * waves +
+    // t / 64).  Consecutive particles share their surroundings, and the expensive ones -- sparse particles beside a
+    // pile in the adjacent row, each with a walk of hundreds of candidates for a handful of hits -- come in runs of
+    // dozens: in storage order one wave would hold them all and walk them one owner at a time while the other
+    // three wait at the round's barrier (measured: that one wave WAS the kernel's duration in the pile-up regime).
+    constexpr int kWaves = kTileW / 64;
+    const int ip = i0 + (t & 63) * kWaves + (t >> 6);
+    const bool livep = ip - i0 < m;
+    const int icp = min(ip, cap - 1);
+    const int cp = cell[icp];
+    const int idp = (DENS && NOISE != SC_NOISE_NONE) ? id[icp] : 0;
+    if (livep) {
+      const int c = cp & kCellMask;
+      e0 = bk(c + 2);
+      b0 = bk(c - 1);
+      b1 = bk(c + w.ncols - 1);
+      e1 = bk(c + w.ncols + 2);
+      bm = bk(c - w.ncols - 1);
+      em = bk(c - w.ncols + 2);
+    }
+    pass_a_body<NOISE, ENUM, DENS, false, CAP>(w, tl, total, txy, list, wkey, t, ip, livep, idp, e0, b0, b1, e1, bm, em, x, y, nbr,
                                           nbr16, cnt, cap, eta, offById, P, sx, sy, tile_id, tileBoundsT);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
