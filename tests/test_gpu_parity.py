@@ -688,7 +688,7 @@ def test_tick_reports_a_bad_promise_and_stays_usable(sc):
 
 
 def test_more_big_buckets_than_the_rank_kernel_lists(sc):
-    """k_rank_big takes the first 1024 big buckets of a tick; the rest is ranked inside the reorder kernel.
+    """k_sort_big takes the first 1024 big buckets of a tick; the rest is ranked inside the reorder kernel.
     1150 cells of 100 particles each, with x ties: the sorted order must still be the reference's."""
     from oracle.neighbors import strip_sort
     rs = np.random.RandomState(8)
@@ -801,7 +801,7 @@ def _cluster_lists(pts, d):
 def test_one_gigantic_bucket(sc):
     """70,000 particles in a patch of one cell: the blocks inside it have tiles of more than 65,535 entries,
     whose neighbor entries are sorted indices in the 32-bit table instead of 16-bit tile slots.  Sort, lists
-    (k_rank_big with 75,000 tasks, the direct search) and one full tick through that table."""
+    (k_sort_big: dozens of sorted chunks, ranks by binary search across them; the direct search) and one full tick through that table."""
     from oracle.neighbors import strip_sort
     from oracle.scene import OracleCrate
     from oracle.tick import tick_core

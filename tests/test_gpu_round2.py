@@ -287,3 +287,65 @@ def test_headless_driver_checkpoints_and_resumes(sc, tmp_path):
     rec_b = np.load(tmp_path / "b" / "variant_00" / "state.npz")
     assert rec_b["ticks"].tolist() == [60]
     assert np.array_equal(rec_b["particles_0"], end_a.particles)
+
+
+# ------------------------------------------------------------------ the pile-up regime
+def pile_up_state(d, seed=21):
+    """What the contract workload turns into: piles of thousands in single cells (spread over the cell, thin along a
+    line, two cells wide), sparse particles in the rows beside them whose windows cover the piles, everything fast
+    enough to change cells every tick, in random storage order."""
+    rs = np.random.RandomState(seed)
+    cell = lambda cx, cy: np.array([cx * d, cy * d])  # noqa: E731
+    parts = [
+        cell(20, 30) + rs.rand(3000, 2) * d * 0.98,                                         # a pile filling its cell
+        cell(40, 12) + np.column_stack((rs.rand(2600) * d * 1.9, 0.93 * d + rs.rand(2600) * d * 0.05)),  # thin, 2 cells
+        cell(60, 50) + np.column_stack((np.full(1500, 0.5 * d), rs.rand(1500) * d * 0.97)),  # exact x ties
+        cell(18, 29) + rs.rand(700, 2) * np.array([6 * d, d]),                               # sparse rows beside them
+        cell(18, 31) + rs.rand(700, 2) * np.array([6 * d, d]),
+        cell(38, 11) + rs.rand(700, 2) * np.array([6 * d, d]),
+        cell(38, 13) + rs.rand(700, 2) * np.array([6 * d, d]),
+        rs.rand(4000, 2) * 0.9 + 0.05,
+    ]
+    p = np.vstack(parts)
+    p = p[rs.permutation(len(p))]
+    v = (rs.rand(len(p), 2) - 0.5) * (2.5 * d / (0.002 * d / 0.01))  # up to ~1.2 cells per tick
+    return p, v
+
+
+@pytest.mark.parametrize("noise", ["none", "counter", "host"])
+def test_pile_up_ticks_match_the_oracle(sc, noise):
+    """Consecutive ticks of a pile-up state -- big buckets sorted chunk by chunk, scrambled waves grouped by cell,
+    tiles beyond the LDS budget with strided threads, cooperative walks with probe skips, renumbered table ranges for
+    pass B and (host mode) for the density pass as its own launch -- each against the oracle from the same state."""
+    from oracle.scene import OracleCrate
+    from oracle.tick import counter_noise_key, counter_noise_u01, remove_outside, tick_core
+    from oracle.world import World
+    d = 0.012
+    p, v = pile_up_state(d)
+    n = len(p)
+    wc = wave_world(sc, d, 0.0 if noise == "none" else 0.1)
+    wc.coefficients["max_particles"] = n
+    crate = sc.Crate(wc, noise=noise, noise_seed=9, capacity=n + 64)  # seeds NumPy's generator like the reference
+    crate.particles = p
+    crate.particle_velocities = v
+    orc = OracleCrate(World(wc.rigid_bodies, [], dict(wc.coefficients)))  # ... and so does this
+    ids = np.arange(n)
+    for t in range(2):
+        crate.physics_tick()
+        for b in orc.rigid_bodies:
+            b.advance(orc.coef["dt"])
+        p, v, ids = remove_outside(p, v, orc.coef["particle_radius"], ids)
+        if noise == "none":
+            eta = None
+        elif noise == "counter":
+            eta = counter_noise_u01(ids, counter_noise_key(9, t))
+        else:
+            eta = lambda total: np.random.rand(total, 2)  # noqa: E731  the stream the device continues (crate.py:169)
+        out = tick_core(p, v, orc.segments, orc.body_states(), orc.coef, eta_u01=eta)
+        gp, gv, gpr, gids = crate.engine.download()
+        assert np.array_equal(gids, ids)
+        assert out["neighbor_counts"].max() == 20 and (out["neighbor_counts"] < 20).any()
+        np.testing.assert_allclose(gp, out["particles"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(gv, out["velocities"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(gpr, out["pressure"], rtol=1e-9, atol=1e-12)
+        p, v = gp, gv
