@@ -466,15 +466,26 @@ void launch_pass_a(sc_ctx* c, int kernel_id) {
     launch_pass_a_cap<NOISE, ENUM, DENS, kTileCapA>(c);
 }
 
+// Big buckets were seen by the last scan the host knows about (an unsynchronised, possibly stale hint in host-mapped
+// memory): the tick sorts its big buckets before ranking them and its cell counts group scrambled waves by cell.
+// Both only cost time when they are wrong; results do not depend on the choice.
+bool piles_expected(const sc_ctx* c) { return c->force_rank_big || *(volatile int*)c->bigHintHost > 0; }
+
 template <int NOISE, bool FUSED, bool MON = false>
 void launch_pass_b(sc_ctx* c, const WallInputs& wn, int part = 0) {
   Bracket br(c, K_FORCE);
   const int cur = (int)(c->tick & 1), nxt = cur ^ 1;
-  hipLaunchKernelGGL((k_pass_b<NOISE, FUSED, MON>), dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters, c->x[1],
-                     c->y[1], c->vx[1], c->vy[1], c->id[1], c->wslotT, c->cellT, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta,
-                     c->offById, c->P, c->sx, c->sy, c->wrec[cur], c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0],
-                     c->tileBoundsT, c->bigHintDev, wn, c->cellS, c->wslotS, c->cellCount, c->wrec[nxt], c->haloL, c->haloR,
-                     c->haloCap, c->monitor, c->tileBand, part);
+  auto launch = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters, c->x[1], c->y[1], c->vx[1],
+                       c->vy[1], c->id[1], c->wslotT, c->cellT, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta, c->offById, c->P,
+                       c->sx, c->sy, c->wrec[cur], c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], c->tileBoundsT,
+                       c->bigHintDev, wn, c->cellS, c->wslotS, c->cellCount, c->wrec[nxt], c->haloL, c->haloR, c->haloCap,
+                       c->monitor, c->tileBand, part);
+  };
+  if (FUSED && piles_expected(c))
+    launch(k_pass_b<NOISE, FUSED, MON, FUSED>);
+  else
+    launch(k_pass_b<NOISE, FUSED, MON, false>);
 }
 
 template <int NOISE>
@@ -733,13 +744,17 @@ int sc_step_begin(sc_ctx* c) {
   }
   {
     Bracket br(c, K_SCATTER);
-    hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->cellS, c->x[0],
-                       c->id[0], Buckets{c->cellStart, c->blockOff}, c->cellCount, c->perm, c->keyX, c->keyId, cap);
+    if (piles_expected(c))
+      hipLaunchKernelGGL(k_scatter<true>, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->cellS, c->x[0],
+                         c->id[0], Buckets{c->cellStart, c->blockOff}, c->cellCount, c->perm, c->keyX, c->keyId, cap);
+    else
+      hipLaunchKernelGGL(k_scatter<false>, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->cellS, c->x[0],
+                         c->id[0], Buckets{c->cellStart, c->blockOff}, c->cellCount, c->perm, c->keyX, c->keyId, cap);
   }
   const int stamp = (int)((c->tick + 1) & 0x3FFFFFFF);
   // big buckets were seen by the last scan the host knows about (an unsynchronised, possibly stale
   // hint in host-mapped memory): rank this tick's big buckets over the whole GPU first
-  if (c->force_rank_big || *(volatile int*)c->bigHintHost > 0) {
+  if (piles_expected(c)) {
     Bracket br(c, K_SCAN);
     hipLaunchKernelGGL(k_sort_big, dim3(4 * c->num_cus), dim3(kSortBlock), 0, c->stream, c->counters, c->bigList,
                        Buckets{c->cellStart, c->blockOff}, c->keyX, c->keyId, c->perm, c->sortedStamp, stamp);

@@ -162,21 +162,28 @@ __device__ __forceinline__ int wall_and_cell(const W& w, double& px, double& py,
 // to kMatchRounds cells.
 constexpr int kScrambledHeads = 28;  // more runs of equal cells than this in a wave: group the lanes by cell
 constexpr int kMatchRounds = 12;
+// GROUP is a launch-time choice (the host launches the grouping variants while the scans report big buckets):
+// inlined into the fused epilogue of pass B the masks of the grouping loop cost that kernel eight more scalar
+// registers than it has -- +2.6 us per tick in the uniform regime for a path that regime never takes.
+template <bool GROUP>
 __device__ __forceinline__ void count_cells(int c, int* __restrict__ cellCount) {
   const int lane = threadIdx.x & 63;
   int key = c >= 0 ? (c & kCellMask) : -1 - lane;
-  LaneRun run = lane_run(key);
-  if (__popcll(__ballot(run.is_head && c >= 0)) > kScrambledHeads) {  // wave-uniform
-    unsigned long long todo = __ballot(c >= 0);
-    for (int it = 0; it < kMatchRounds && todo; ++it) {
-      const int leader = __builtin_amdgcn_readfirstlane(__ffsll(todo) - 1);
-      const int kc = __builtin_amdgcn_readlane(key, leader);
-      const unsigned long long grp = __ballot(key == kc);
-      if (lane == leader) atomicAdd(&cellCount[kc], (int)__popcll(grp));
-      if (key == kc) key = -1 - lane;  // counted
-      todo &= ~grp;
+  const LaneRun run = lane_run(key);
+  if constexpr (GROUP) {
+    if (__popcll(__ballot(run.is_head && c >= 0)) > kScrambledHeads) {  // wave-uniform
+      unsigned long long todo = __ballot(key >= 0);
+      for (int it = 0; it < kMatchRounds && todo; ++it) {
+        const int leader = __builtin_amdgcn_readfirstlane(__ffsll(todo) - 1);
+        const int kc = __builtin_amdgcn_readlane(key, leader);
+        const unsigned long long grp = __ballot(key == kc);
+        if (lane == leader) atomicAdd(&cellCount[kc], (int)__popcll(grp));
+        if (key == kc) key = -1;  // counted
+        todo &= ~grp;
+      }
+      if (key >= 0) atomicAdd(&cellCount[key], 1);  // cells beyond the rounds: one by one
+      return;
     }
-    run = lane_run(key);
   }
   if (run.is_head && key >= 0) atomicAdd(&cellCount[key], run.len);
 }
@@ -202,7 +209,7 @@ __global__ void __launch_bounds__(kBlock) k_wall_bin(World w, int* __restrict__ 
       }
     }
   }
-  count_cells(c, cellCount);
+  count_cells<true>(c, cellCount);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -485,6 +492,7 @@ __device__ __forceinline__ int chunk_of_block() {
 #endif
 }
 
+template <bool GROUP>
 __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ counters, const int* __restrict__ cellS,
                                                     const double* __restrict__ xS, const int* __restrict__ idS,
                                                     Buckets bk, int* __restrict__ cellCount,
@@ -502,10 +510,10 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ coun
   // stay near their cells.  In a pile-up they do not (the contract workload's particles cross more than a cell per
   // tick by then): runs shrink to one or two lanes and a cell of thousands takes thousands of returning atomics on
   // one address.  A wave that finds itself that scrambled (many run heads) groups its lanes by cell whatever their
-  // order, one atomic per cell, for up to kMatchRounds cells; what is left goes by runs as usual.
+  // order, one atomic per cell, for up to kMatchRounds cells; what is left goes one by one.
   int pos = -1;
   LaneRun run = lane_run(c >= 0 ? c : -1 - lane);
-  const bool scrambled = __popcll(__ballot(run.is_head && c >= 0)) > kScrambledHeads;  // wave-uniform
+  const bool scrambled = GROUP && __popcll(__ballot(run.is_head && c >= 0)) > kScrambledHeads;  // wave-uniform
   if (scrambled) {
     unsigned long long todo = __ballot(c >= 0);
     int my_leader = -1, my_off = 0, my_len = 0;
@@ -520,18 +528,21 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ coun
       }
       todo &= ~grp;
     }
+    if (c >= 0 && my_leader < 0) {  // cells beyond the rounds: one by one
+      my_leader = lane;
+      my_len = 1;
+    }
     int base = 0;  // the groups' atomics leave together
     if (my_leader == lane) base = bk(c) + atomicSub(&cellCount[c], my_len) - my_len;
     base = __shfl(base, my_leader >= 0 ? my_leader : lane, 64);
-    if (my_leader >= 0) pos = base + my_off;
+    pos = base + my_off;
+  } else {
+    int base = 0;
+    if (run.is_head && c >= 0) base = bk(c) + atomicSub(&cellCount[c], run.len) - run.len;
+    base = __shfl(base, run.head, 64);
+    pos = base + (lane - run.head);
   }
-  const bool rest = c >= 0 && pos < 0;
-  if (scrambled) run = lane_run(rest ? c : -1 - lane);
-  int base = 0;
-  if (run.is_head && rest) base = bk(c) + atomicSub(&cellCount[c], run.len) - run.len;
-  base = __shfl(base, run.head, 64);
   if (c < 0) return;
-  if (rest) pos = base + (lane - run.head);
   perm[pos] = i;
   keyX[pos] = xi;
   keyId[pos] = idi;
@@ -871,7 +882,7 @@ __global__ void __launch_bounds__(kBlock)
     if (sendR) *reinterpret_cast<int*>(sendR) = 0;
   };
   if (FUSED) {
-    count_cells(cnext, cellCount);  // every lane of the wave takes part
+    count_cells<true>(cnext, cellCount);  // every lane of the wave takes part
     if (blockIdx.x == 0 && threadIdx.x == 0) finish();
     return;
   }

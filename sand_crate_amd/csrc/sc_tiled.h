@@ -887,7 +887,8 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
 // index, bucket count -- sc_kernels.h: wall_and_cell) on the freshly integrated position, with the
 // next tick's walls `wn` (sc_set_next_inputs).  That tick then starts at the bucket scan: one launch
 // and one read+write of the positions less per tick.
-template <int NOISE, bool FUSED, bool MON = false>
+// GROUP: the fused cell count groups scrambled waves by cell (sc_kernels.h: count_cells); launched while big buckets exist
+template <int NOISE, bool FUSED, bool MON = false, bool GROUP = false>
 __global__ void __launch_bounds__(kTileW)
     k_pass_b(World w, int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
              const double* __restrict__ vx, const double* __restrict__ vy, const int* __restrict__ id,
@@ -1048,7 +1049,7 @@ __global__ void __launch_bounds__(kTileW)
       cellS[i] = cnext;
       if (cnext >= 0) wslotS[i] = wsn;
     }
-    count_cells(cnext, cellCount);  // every lane of the wave takes part
+    count_cells<GROUP>(cnext, cellCount);  // every lane of the wave takes part
     // slabs: the coming tick's halo message is packed here too (same rule and same pre-wall-fix position as
     // k_halo_pack); a workgroup-uniform branch, every lane of the wave takes part
     if (wn.slab && haloL)
