@@ -114,6 +114,17 @@ __device__ __forceinline__ int tile_of_block() {
   return xcd * q + min(xcd, r) + (b >> 3);
 }
 
+// The same runs, walked from both ends towards the middle (the search).  Blocks start in index order and the
+// kernel ends with its slowest block: in a pile-up those are the blocks beside the piles along the floor and the
+// ceiling -- the first tiles of the first XCD's run and the last tiles of the last one's, which in plain order start
+// when everything else is nearly done.  Two contiguous fronts per XCD keep the overlaps in its L2 as before.
+__device__ __forceinline__ int tile_of_block_ends_first() {
+  const int nb = gridDim.x, b = blockIdx.x;
+  const int q = nb >> 3, r = nb & 7, xcd = b & 7;
+  const int start = xcd * q + min(xcd, r), len = q + (xcd < r ? 1 : 0), l = b >> 3;
+  return (l & 1) ? start + len - 1 - (l >> 1) : start + (l >> 1);
+}
+
 // Phases 3-5 of pass A for one particle.  LDS: where the tile is (compile time, see the header).
 template <int NOISE, bool ENUM, bool DENS, bool LDS, int CAP>
 __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, const int total, XY* txy,
@@ -586,7 +597,7 @@ __global__ void __launch_bounds__(kTileW)
   __shared__ int wkey[6 * (kTileW / 64)];  // the windowed scans' round keys (2 per wave); the lists' reach per range (6 per wave)
 
   const int t = threadIdx.x;
-  const int tile_id = tile_of_block();
+  const int tile_id = tile_of_block_ends_first();
   const int i0 = tile_id * kTileW;
   const int i = i0 + t;
   SC_STAMP(0, 0);
