@@ -248,3 +248,22 @@ def test_particle_too_fast_for_the_overlapped_message_is_reported(sc):
     chain.run(3)
     with pytest.raises(NativeError, match="missed the overlapped halo message"):
         chain.synchronize()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_slabs_in_a_pile_up_state_equal_the_single_domain(sc, overlap):
+    """The pile-up paths (sorted big buckets, grouped cell counts, strided dense tiles, renumbered table ranges) under
+    the slab decomposition: ghosts next to piles, halo messages packed by the grouping force kernel."""
+    from sand_crate_amd.slab import SlabChain
+    from test_gpu_parity import wave_world
+    from test_gpu_round2 import pile_up_state
+    d, ticks = 0.012, 4
+    p, v = pile_up_state(d)
+    wc = wave_world(sc, d, 0.1)
+    wc.coefficients["max_particles"] = len(p)
+    single, _ = single_domain(sc, wc, p, v, ticks)
+    chain = SlabChain(copy.deepcopy(wc), p, v, 3, noise="counter", noise_seed=1, overlap=overlap)
+    chain.run(ticks)
+    chain.synchronize()
+    assert sum(chain.owned_counts()) == len(single[3])
+    assert_chain_equals_single(chain, single)
