@@ -346,6 +346,13 @@ int build_world(sc_ctx* c, World& w, const sc_params& p, int nseg, const Seg* se
   w.own_lo = c->slab ? c->own_lo : std::numeric_limits<long long>::min();
   w.own_hi = c->slab ? c->own_hi : std::numeric_limits<long long>::max();
   w.halo = c->halo;
+  {  // where the particles are expected to end: for slabs a recent tick's live count (blocks beyond it are placed one by one)
+    const int64_t done = *(volatile int*)(c->bigHintHost + 1), published = *(volatile int*)(c->bigHintHost + 2);
+    const int64_t bound = launch_bound(c);
+    w.live_hint = (int)(c->slab && published > 0 && done > c->live_hint_from
+                            ? std::min<int64_t>(bound, (int64_t)published + 2048)
+                            : bound);
+  }
   w.has_left = c->has_left;
   w.has_right = c->has_right;
   return SC_OK;
@@ -746,10 +753,10 @@ int sc_step_begin(sc_ctx* c) {
     Bracket br(c, K_SCATTER);
     if (piles_expected(c))
       hipLaunchKernelGGL(k_scatter<true>, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->cellS, c->x[0],
-                         c->id[0], Buckets{c->cellStart, c->blockOff}, c->cellCount, c->perm, c->keyX, c->keyId, cap);
+                         c->id[0], Buckets{c->cellStart, c->blockOff}, c->cellCount, c->perm, c->keyX, c->keyId, cap, w.live_hint);
     else
       hipLaunchKernelGGL(k_scatter<false>, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->cellS, c->x[0],
-                         c->id[0], Buckets{c->cellStart, c->blockOff}, c->cellCount, c->perm, c->keyX, c->keyId, cap);
+                         c->id[0], Buckets{c->cellStart, c->blockOff}, c->cellCount, c->perm, c->keyX, c->keyId, cap, w.live_hint);
   }
   const int stamp = (int)((c->tick + 1) & 0x3FFFFFFF);
   // big buckets were seen by the last scan the host knows about (an unsynchronised, possibly stale
@@ -764,7 +771,7 @@ int sc_step_begin(sc_ctx* c) {
     hipLaunchKernelGGL(k_reorder, dim3((int)std::max<int64_t>(1, (launch_bound(c) + kReorderBlock - 1) / kReorderBlock)),
                        dim3(kReorderBlock), 0, c->stream, c->counters, c->perm, c->keyX, c->keyId,
                        c->cellS, Buckets{c->cellStart, c->blockOff}, c->wslotS, c->y[0], c->vx[0], c->vy[0], c->x[1], c->y[1], c->vx[1],
-                       c->vy[1], c->id[1], c->cellT, c->wslotT, c->sortedStamp, stamp, w.ncols, c->tileBounds);
+                       c->vy[1], c->id[1], c->cellT, c->wslotT, c->sortedStamp, stamp, w.ncols, c->tileBounds, w.live_hint);
   }
   // SC_NOISE_HOST (and the stand-alone search) stop after the lists: the host's rand block can only be
   // indexed once every count is known.  Otherwise the search and pass A are one launch.

@@ -57,6 +57,8 @@ struct World {
   // floor(x / d) of the position a particle has when the tick starts.
   long long own_lo, own_hi;  // owned columns [own_lo, own_hi)
   int slab, halo;            // slab mode on/off; ghost band width in columns
+  int live_hint;             // particles expected to be live (a recent tick's count plus slack; the launch bound when
+                             // unknown): only the XCD-aware placement of blocks uses it, never a result
   int has_left, has_right;
   Seg seg[kMaxSeg];
   Seg pad[2 * kMaxSeg];

@@ -482,11 +482,14 @@ __global__ void __launch_bounds__(kSortBlock)
 // XCD-aware block -> chunk mapping (same idea as sc_tiled.h: tile_of_block): workgroups are dealt round-robin over
 // the 8 XCDs, so giving every XCD one contiguous run of chunks keeps neighboring chunks -- whose gathers and
 // scattered stores fall into the same cache lines -- inside one L2.  Placement is a speed matter only.
-__device__ __forceinline__ int chunk_of_block() {
+// `live_hint`: the particles expected to be live (World::live_hint): only the blocks that hold them are dealt into
+// runs, the rest of a grid sized by capacity keeps its own index.
+__device__ __forceinline__ int chunk_of_block(int live_hint) {
 #ifdef SC_NO_XCD_CHUNKS
   return blockIdx.x;
 #else
-  const int nb = gridDim.x, b = blockIdx.x;
+  const int nb = min((int)gridDim.x, (int)((live_hint + blockDim.x - 1) / blockDim.x)), b = blockIdx.x;
+  if (b >= nb) return b;
   const int q = nb >> 3, r = nb & 7, xcd = b & 7;
   return xcd * q + min(xcd, r) + (b >> 3);
 #endif
@@ -497,8 +500,8 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ coun
                                                     const double* __restrict__ xS, const int* __restrict__ idS,
                                                     Buckets bk, int* __restrict__ cellCount,
                                                     int* __restrict__ perm, double* __restrict__ keyX,
-                                                    int* __restrict__ keyId, int cap) {
-  int i = chunk_of_block() * blockDim.x + threadIdx.x;
+                                                    int* __restrict__ keyId, int cap, int live_hint) {
+  int i = chunk_of_block(live_hint) * blockDim.x + threadIdx.x;
   const int ic = min(i, cap - 1);  // loads that do not depend on the stored count go out first
   int c = cellS[ic];
   const double xi = xS[ic];
@@ -567,11 +570,11 @@ __global__ void __launch_bounds__(kReorderBlock)
               const double* __restrict__ vyS, double* __restrict__ xT, double* __restrict__ yT,
               double* __restrict__ vxT, double* __restrict__ vyT, int* __restrict__ idT, int* __restrict__ cellT,
               int* __restrict__ wslotT, const int* __restrict__ sortedStamp, int stamp, int ncols,
-              int* __restrict__ tileBounds) {
+              int* __restrict__ tileBounds, int live_hint) {
   __shared__ double ckx[kRankChunk];
   __shared__ int cki[kRankChunk];
   __shared__ int pick;
-  const int s = chunk_of_block() * blockDim.x + threadIdx.x;
+  const int s = chunk_of_block(live_hint) * blockDim.x + threadIdx.x;
   const int nlive = counters[C_NT];
   const bool live = s < nlive;
   int i = 0, idi = 0, cpacked = 0, c = 0, wsi = 0, b = 0, e = 0;
