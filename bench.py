@@ -7,7 +7,7 @@ Workload.  N=1: BASELINE.json configs[2], the largest
 1,048,576 synthetic uniformly seeded particles in the wave_machine.yaml world (its coefficients, both rigid
 bodies incl. the motored wall, no particle source), particle diameter d = sqrt(12 / (pi P_total)) so that a
 particle has ~12 neighbors, dt scaled with d, collider_noise_level 0.1 from a counter-based device RNG.
-N=4 / N=8: configs[3] / configs[4] (4,194,304 / 16,777,216 particles in all, x-slabs, halo exchange per tick);
+N=4 / N=8: configs[3] / configs[4] (4,194,304 / 16,777,216 particles in all, slabs of rows, halo exchange per tick);
 N=2: 1,048,576 per GPU.  A step is one `physics_tick` of all particles; state is resident in HBM before the
 timed region and nothing is read back inside it.  The W+K-step measurement is repeated (--repeats, default 5)
 from the same initial state; `value` is the median repetition, all repetitions are listed.
@@ -198,6 +198,9 @@ def main() -> None:
     ap.add_argument("--cpu-sample", type=int, default=262144,
                     help="particles in the CPU baseline tick (0 = skip); 262,144 is one tick of ~13 s")
     ap.add_argument("--noise", default="counter", choices=["counter", "none"])
+    ap.add_argument("--slab-axis", default="y", choices=["x", "y"],
+                    help="N > 1: cut the domain into slabs of rows (y: the halo bands are the ends of the sorted order, the "
+                         "halo overlap costs least) or of columns (x)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: every rank uses cuda:0 and the gloo backend (halo staged through the "
                          "host), to exercise the N > 1 code path on a one-GPU box; the numbers mean nothing")
@@ -244,7 +247,7 @@ def main() -> None:
             if slab_sim:
                 slab_sim[0].reload(p, v)
             else:
-                slab_sim.append(SlabCrate(w, p, v, device=local_rank, noise=args.noise, noise_seed=1))
+                slab_sim.append(SlabCrate(w, p, v, device=local_rank, noise=args.noise, noise_seed=1, axis=args.slab_axis))
             return slab_sim[0]
         s = sc.Crate(w, device=local_rank, noise=args.noise, noise_seed=1, capacity=n_total + 1024)
         s.particles = p
@@ -330,7 +333,7 @@ def main() -> None:
                                    f"wave_machine.yaml world incl. the motored wall, d=sqrt(12/(pi*P)) (~12 neighbors), "
                                    f"collider noise 0.1 ({args.noise} RNG), ticks {args.warmup}..{args.warmup + args.steps - 1}",
                        "particles_per_gpu": per_gpu, "particles_total": n_total, "live_after_run": int(n_live),
-                       "parallelism": "single GPU" if world == 1 else f"{world} x-slabs, halo exchange per tick",
+                       "parallelism": "single GPU" if world == 1 else f"{world} slabs of {'rows' if args.slab_axis == 'y' else 'columns'}, halo exchange per tick",
                        "transport": transport}}
     if rank == 0 and args.no_kernel_events:
         base["note"] = "no per-kernel events"

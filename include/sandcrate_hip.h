@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 2
+#define SC_ABI_VERSION 3
 #define SC_MAX_NEIGHBORS 20 /* collision_detector.py:6  MAX_ALLOWED_NEIGHBORS */
 #define SC_MAX_SEGMENTS 16  /* wall segments of all rigid bodies together (scenes use 6 and 8) */
 #define SC_MAX_BODIES 8
@@ -188,7 +188,7 @@ int sc_reset_timing(sc_ctx* ctx);
 int sc_get_timing(sc_ctx* ctx, double* ms /*[SC_NUM_KERNELS]*/, int64_t* launches /*[SC_NUM_KERNELS]*/);
 const char* sc_kernel_name(int index);
 
-/* Multi-GPU x-slabs (no reference counterpart).  One context per GPU owns the
+/* Multi-GPU slabs (of columns, or of rows: sc_set_slab_axis) (no reference counterpart).  One context per GPU owns the
  * grid columns [col_lo, col_hi), column = floor(x / diameter) of the position a particle has when
  * the tick starts.  Particles within `halo` columns outside the slab are ghosts: they take part in
  * the wall fix, the neighbor search and pass A exactly like owned particles, are never integrated,
@@ -211,6 +211,13 @@ const char* sc_kernel_name(int index);
  * steady-state slab tick is then:  exchange -> sc_halo_unpack -> sc_tick(now, next).  Calling sc_halo_pack
  * for a tick that was packed this way is refused (SC_ERR_STATE). */
 int sc_set_slab(sc_ctx* ctx, int64_t col_lo, int64_t col_hi, int32_t halo, int32_t has_left, int32_t has_right);
+/* Which way the domain is cut: axis 0 (the default) -- slabs are ranges of COLUMNS floor(x / d), "left" / "right"
+ * are the neighbors towards smaller / larger x; axis 1 -- ranges of ROWS floor(y / d), neighbors towards smaller /
+ * larger y (sc_set_slab's col_lo / col_hi, the histogram of sc_column_histogram and `halo` then count rows).  The
+ * sorted order is row-major, so with rows the halo bands are the first and last few blocks of it: the blocks
+ * that may pack halo records (sc_set_halo_overlap) are a percent of all instead of a third.  Call before
+ * sc_set_slab; results do not depend on the axis. */
+int sc_set_slab_axis(sc_ctx* ctx, int32_t axis);
 int sc_upload_state_ids(sc_ctx* ctx, const double* xy, const double* vxy, const int64_t* ids, int64_t n);
 int sc_halo_pack(sc_ctx* ctx, double* dev_left, double* dev_right, int64_t capacity_records);
 /* Message sizes.  A message need not carry the whole buffer: sc_halo_sizes gives, for the exchange of the coming

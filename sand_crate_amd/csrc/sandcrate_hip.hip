@@ -153,6 +153,7 @@ struct sc_ctx {
   double custom_d = 0;
   bool slab = false;
   long long own_lo = 0, own_hi = 0;
+  int slab_axis = 0;  // 0: slabs of columns (x), 1: of rows (y)
   int halo = 0, has_left = 0, has_right = 0;
   int* stage_ids = nullptr;
   std::vector<int> ids_host;
@@ -313,14 +314,17 @@ int build_world(sc_ctx* c, World& w, const sc_params& p, int nseg, const Seg* se
     w.ccd_skip2 = (2 * w.d) * (2 * w.d) * (1 - 1e-6);
     long long cmin = (long long)std::floor(w.lo / w.d) - 3;
     long long cmax = (long long)std::floor(w.hi / w.d) + 3;
-    w.row0 = cmin - 1;
-    w.nrows = (int)(cmax - cmin + 1) + 2;
-    long long ccmin = cmin, ccmax = cmax;
-    if (c->slab) {  // local columns: the slab, its ghost band, one column of slack for the wall fix
-      ccmin = std::max(cmin, c->own_lo - c->halo - 1);
-      ccmax = std::min(cmax, c->own_hi + c->halo);
-      if (ccmax < ccmin) ccmax = ccmin;
+    // slabs keep a local grid: the slab, its ghost band, one column / row of slack for the wall fix
+    long long ccmin = cmin, ccmax = cmax, rrmin = cmin, rrmax = cmax;
+    if (c->slab) {
+      long long& lo = c->slab_axis ? rrmin : ccmin;
+      long long& hi = c->slab_axis ? rrmax : ccmax;
+      lo = std::max(cmin, c->own_lo - c->halo - 1);
+      hi = std::min(cmax, c->own_hi + c->halo);
+      if (hi < lo) hi = lo;
     }
+    w.row0 = rrmin - 1;
+    w.nrows = (int)(rrmax - rrmin + 1) + 2;
     w.col0 = ccmin - 1;
     w.ncols = (int)(ccmax - ccmin + 1) + 2;
   }
@@ -343,6 +347,8 @@ int build_world(sc_ctx* c, World& w, const sc_params& p, int nseg, const Seg* se
   w.tick = (int)tick;
   w.noise_key = mix64(c->seed + (uint64_t)(tick + 1) * kGold);
   w.slab = c->slab ? 1 : 0;
+  w.slab_axis = c->slab ? c->slab_axis : 0;
+  w.band_margin = w.slab_axis ? kBandMarginRows : kBandMarginColumns;
   w.own_lo = c->slab ? c->own_lo : std::numeric_limits<long long>::min();
   w.own_hi = c->slab ? c->own_hi : std::numeric_limits<long long>::max();
   w.halo = c->halo;
@@ -371,7 +377,7 @@ WallInputs wall_inputs_of(const World& w) {
   std::memset(&k, 0, sizeof k);
   k.r = w.r; k.d = w.d; k.lo = w.lo; k.hi = w.hi; k.t_wall = w.t_wall; k.touch_box = w.touch_box; k.far_box = w.far_box;
   k.row0 = w.row0; k.col0 = w.col0; k.own_lo = w.own_lo; k.own_hi = w.own_hi;
-  k.nrows = w.nrows; k.ncols = w.ncols; k.nseg = w.nseg; k.nbody = w.nbody; k.slab = w.slab;
+  k.nrows = w.nrows; k.ncols = w.ncols; k.nseg = w.nseg; k.nbody = w.nbody; k.slab = w.slab; k.slab_axis = w.slab_axis;
   std::memcpy(k.seg, w.seg, sizeof k.seg);
   std::memcpy(k.body, w.body, sizeof k.body);
   return k;
@@ -391,8 +397,8 @@ int check_flags(int flags) {
   if (flags & F_HALO_OVERFLOW) return fail(SC_ERR_CAPACITY, "a halo buffer was too small; ghost particles were lost");
   if (flags & F_CAPACITY) return fail(SC_ERR_CAPACITY, "received halo particles exceed the context capacity");
   if (flags & F_HALO_LATE)
-    return fail(SC_ERR_DOMAIN, "a particle moved more than %d columns in one tick and missed the overlapped halo message",
-                kBandMargin);
+    return fail(SC_ERR_DOMAIN, "a particle moved more than the band margin (%d columns / %d rows) in one tick and missed the "
+                "overlapped halo message: run without halo overlap", kBandMarginColumns, kBandMarginRows);
   return SC_OK;
 }
 
@@ -480,19 +486,33 @@ bool piles_expected(const sc_ctx* c) { return c->force_rank_big || *(volatile in
 
 template <int NOISE, bool FUSED, bool MON = false>
 void launch_pass_b(sc_ctx* c, const WallInputs& wn, int part = 0) {
-  Bracket br(c, K_FORCE);
   const int cur = (int)(c->tick & 1), nxt = cur ^ 1;
+  // slabs of rows: the band blocks lie within (ghost rows + halo + margin) rows of either end of the sorted order; the
+  // window takes twice the blocks those rows hold on average (a band block outside it is handled by part 2 and, should
+  // it have anything to pack, reported like a particle that was too fast)
+  int bandw = 0;
+  if (part && c->slab_axis == 1) {
+    const int64_t rows = std::max<int64_t>(1, std::min<int64_t>(c->own_hi, c->w.row0 + c->w.nrows) - std::max<int64_t>(c->own_lo, c->w.row0));
+    const int64_t band_rows = 2 * c->halo + kBandMarginRows + 2;
+    bandw = (int)std::min<int64_t>(tile_grid(c), 2 * band_rows * (c->w.live_hint / rows + 1) / kTileW + 16);
+  }
+  const int grid = part == 1 && bandw ? 2 * bandw : tile_grid(c);
+  hipStream_t stream = c->stream;
   auto launch = [&](auto kernel) {
-    hipLaunchKernelGGL(kernel, dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters, c->x[1], c->y[1], c->vx[1],
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kTileW), 0, stream, c->w, c->counters, c->x[1], c->y[1], c->vx[1],
                        c->vy[1], c->id[1], c->wslotT, c->cellT, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta, c->offById, c->P,
                        c->sx, c->sy, c->wrec[cur], c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], c->tileBoundsT,
                        c->bigHintDev, wn, c->cellS, c->wslotS, c->cellCount, c->wrec[nxt], c->haloL, c->haloR, c->haloCap,
-                       c->monitor, c->tileBand, part);
+                       c->monitor, c->tileBand, part, bandw);
   };
-  if (FUSED && piles_expected(c))
-    launch(k_pass_b<NOISE, FUSED, MON, FUSED>);
-  else
-    launch(k_pass_b<NOISE, FUSED, MON, false>);
+  auto pick = [&]() {
+    if (FUSED && piles_expected(c))
+      launch(k_pass_b<NOISE, FUSED, MON, FUSED>);
+    else
+      launch(k_pass_b<NOISE, FUSED, MON, false>);
+  };
+  Bracket br(c, K_FORCE);
+  pick();
 }
 
 template <int NOISE>
@@ -1200,6 +1220,15 @@ int sc_points_to_segments(int device, const double* xy, int64_t n, const double*
 
 // ---- multi-GPU slabs ---------------------------------------------------------------------------
 
+int sc_set_slab_axis(sc_ctx* c, int32_t axis) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  if (c->in_step) return fail(SC_ERR_STATE, "slab cannot change inside a tick");
+  if (axis != 0 && axis != 1) return fail(SC_ERR_ARG, "slab axis: 0 (columns of x) or 1 (rows of y)");
+  c->slab_axis = axis;
+  c->halo_ring_from = c->tick;
+  return SC_OK;
+}
+
 int sc_set_slab(sc_ctx* c, int64_t col_lo, int64_t col_hi, int32_t halo, int32_t has_left, int32_t has_right) {
   if (!c) return fail(SC_ERR_ARG, "null context");
   if (c->in_step) return fail(SC_ERR_STATE, "slab cannot change inside a tick");
@@ -1266,8 +1295,8 @@ int sc_column_histogram(sc_ctx* c, int64_t col0, int32_t ncols, int64_t* hist) {
   }
   HIPCHK(hipMemsetAsync(c->colHist, 0, ncols * sizeof(int), c->stream));
   const double d = c->custom_grid ? c->custom_d : c->params.particle_radius * 2;
-  hipLaunchKernelGGL(k_column_histogram, dim3(grid_for(launch_bound(c))), dim3(kBlock), 0, c->stream, c->counters, c->x[0], d,
-                     (long long)col0, (int)ncols, c->colHist);
+  hipLaunchKernelGGL(k_column_histogram, dim3(grid_for(launch_bound(c))), dim3(kBlock), 0, c->stream, c->counters, c->x[0],
+                     c->slab_axis ? c->y[0] : c->x[0], d, (long long)col0, (int)ncols, c->colHist);
   std::vector<int> h(ncols);
   HIPCHK(hipMemcpyAsync(h.data(), c->colHist, ncols * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1332,8 +1361,9 @@ int sc_halo_unpack(sc_ctx* c, const double* from_left, int64_t left_records, con
 
 static int ensure_side_stream(sc_ctx* c) {
   if (!c->side_stream) HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-  if (!c->ev_band) HIPCHK(hipEventCreateWithFlags(&c->ev_band, hipEventDisableTiming));
-  if (!c->ev_xchg) HIPCHK(hipEventCreateWithFlags(&c->ev_xchg, hipEventDisableTiming));
+  // (device-side ordering only: without the system-scope fence an event between two kernels costs ~1 us instead of ~10)
+  if (!c->ev_band) HIPCHK(hipEventCreateWithFlags(&c->ev_band, hipEventDisableTiming | hipEventDisableSystemFence));
+  if (!c->ev_xchg) HIPCHK(hipEventCreateWithFlags(&c->ev_xchg, hipEventDisableTiming | hipEventDisableSystemFence));
   return SC_OK;
 }
 

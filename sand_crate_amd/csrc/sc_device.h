@@ -53,10 +53,12 @@ struct World {
   int noise_mode;
   int tick;
   unsigned long long noise_key;
-  // slab decomposition (single GPU: slab = 0 and every column is owned).  Columns are
-  // floor(x / d) of the position a particle has when the tick starts.
-  long long own_lo, own_hi;  // owned columns [own_lo, own_hi)
-  int slab, halo;            // slab mode on/off; ghost band width in columns
+  // slab decomposition (single GPU: slab = 0 and everything is owned).  A particle's column / row is
+  // floor(x / d) / floor(y / d) of the position it has when the tick starts.
+  long long own_lo, own_hi;  // owned columns (slab_axis 0) or rows (1): [own_lo, own_hi)
+  int slab, halo;            // slab mode on/off; ghost band width in columns / rows
+  int slab_axis;             // 0: slabs are ranges of columns floor(x / d); 1: of rows floor(y / d)
+  int band_margin;           // halo overlap: how far from the halo band a block still counts as a band block
   int live_hint;             // particles expected to be live (a recent tick's count plus slack; the launch bound when
                              // unknown): only the XCD-aware placement of blocks uses it, never a result
   int has_left, has_right;
@@ -71,7 +73,7 @@ struct World {
 struct WallInputs {
   double r, d, lo, hi, t_wall, touch_box, far_box;
   long long row0, col0, own_lo, own_hi;
-  int nrows, ncols, nseg, nbody, slab, pad_;
+  int nrows, ncols, nseg, nbody, slab, slab_axis;
   Seg seg[kMaxSeg];
   BodyK body[kMaxBody];
 };
@@ -95,7 +97,9 @@ enum Counter {
 
 enum Flag { F_OUT_OF_GRID = 1, F_NAN = 2, F_HALO_OVERFLOW = 4, F_CAPACITY = 8, F_HALO_LATE = 16 };
 
-constexpr int kBandMargin = 2;  // columns a particle may move in one tick and still be packed in time (halo overlap)
+// columns / rows a particle may move in one tick and still be packed in time (halo overlap).  With slabs of rows the
+// band blocks are few whatever the margin; with columns every row has them, and each column of margin adds as many.
+constexpr int kBandMarginColumns = 2, kBandMarginRows = 8;
 
 constexpr int kGhostBit = 1 << 30;  // set in a particle's packed cell index when it is a ghost
 constexpr int kCellMask = kGhostBit - 1;

@@ -69,7 +69,7 @@ __device__ __forceinline__ int wall_and_cell(const W& w, double& px, double& py,
   if (px < w.lo || px > w.hi || py < w.lo || py > w.hi) return -1;  // crate.py:152 (dead ghosts carry x = +inf)
   bool ghost = false;
   if (w.slab) {
-    long long col = (long long)floor(px / w.d);
+    long long col = (long long)floor((w.slab_axis ? py : px) / w.d);
     ghost = col < w.own_lo || col >= w.own_hi;
   }
   // bounding-box reject (exact-safe: the boxes are inflated far beyond rounding error)
@@ -795,12 +795,12 @@ __device__ __forceinline__ int halo_slot(bool want, double* __restrict__ buf) {
 // `late`: the message has already left (halo overlap: this is an interior tile); a particle that belongs in it
 // after all moved further than the band margin allows -- flagged, never silently dropped.
 __device__ __forceinline__ void halo_pack_one(bool on, double px, double py, double pvx, double pvy, int pid, double d,
-                                              long long own_lo, long long own_hi, int halo, int has_left,
+                                              int axis, long long own_lo, long long own_hi, int halo, int has_left,
                                               int has_right, double* __restrict__ left, double* __restrict__ right,
                                               int cap, int* __restrict__ counters, bool late = false) {
   bool toL = false, toR = false;
   if (on && fabs(px) < 1e300) {  // not a dead ghost copy (x = +inf), not NaN
-    const long long col = (long long)floor(px / d);
+    const long long col = (long long)floor((axis ? py : px) / d);
     toL = has_left && col < own_lo + halo;
     toR = has_right && col >= own_hi - halo;
   }
@@ -827,7 +827,7 @@ __global__ void __launch_bounds__(kBlock)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int ic = min(i, capS - 1);
   const bool on = i < counters[C_NS];
-  halo_pack_one(on, x[ic], y[ic], vx[ic], vy[ic], id[ic], w.d, w.own_lo, w.own_hi, w.halo, w.has_left, w.has_right, left,
+  halo_pack_one(on, x[ic], y[ic], vx[ic], vy[ic], id[ic], w.d, w.slab_axis, w.own_lo, w.own_hi, w.halo, w.has_left, w.has_right, left,
                 right, cap, counters);
 }
 
@@ -902,13 +902,12 @@ __global__ void __launch_bounds__(kBlock)
 // Stored live particles per grid column, clamped into [col0, col0 + ncols): across the ranks every particle is
 // stored live exactly once, so the sum of the ranks' histograms is the global one (slab re-balancing).
 __global__ void __launch_bounds__(kBlock)
-    k_column_histogram(const int* __restrict__ counters, const double* __restrict__ x, double d, long long col0, int ncols,
-                       int* __restrict__ hist) {
+    k_column_histogram(const int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ coord,
+                       double d, long long col0, int ncols, int* __restrict__ hist) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= counters[C_NS]) return;
-  const double px = x[i];
-  if (!(fabs(px) < 1e300)) return;  // a dead ghost copy: its owner counts the particle
-  const long long col = (long long)floor(px / d);
+  if (!(fabs(x[i]) < 1e300)) return;  // a dead ghost copy: its owner counts the particle
+  const long long col = (long long)floor(coord[i] / d);  // coord: x (slabs of columns) or y (slabs of rows)
   const long long k = col - col0;
   atomicAdd(&hist[k < 0 ? 0 : (k >= ncols ? ncols - 1 : (int)k)], 1);
 }

@@ -620,14 +620,14 @@ __global__ void __launch_bounds__(kTileW)
   const bool live = t < m;
 
   // slabs: does this block hold a particle that may end the tick in a halo band (its column within the band
-  // plus kBandMargin of a cut)?  Pass B runs those blocks first and lets the halo exchange start while the
+  // plus the band margin of a cut)?  Pass B runs those blocks first and lets the halo exchange start while the
   // interior blocks are still computing (sc_set_halo_overlap).
   if (ENUM && w.slab) {
     bool band = false;
     if (live) {
       const int c = cpacked & kCellMask;
-      const long long col = (long long)(c % w.ncols) + w.col0;
-      band = (w.has_left && col < w.own_lo + w.halo + kBandMargin) || (w.has_right && col >= w.own_hi - w.halo - kBandMargin);
+      const long long col = w.slab_axis ? (long long)(c / w.ncols) + w.row0 : (long long)(c % w.ncols) + w.col0;
+      band = (w.has_left && col < w.own_lo + w.halo + w.band_margin) || (w.has_right && col >= w.own_hi - w.halo - w.band_margin);
     }
     const int any = __syncthreads_or(band);
     if (t == 0) tileBand[tile_id] = any;
@@ -919,14 +919,26 @@ __global__ void __launch_bounds__(kTileW)
              WallInputs wn, int* __restrict__ cellS, int* __restrict__ wslotS, int* __restrict__ cellCount,
              double* __restrict__ wrec_next, double* __restrict__ haloL,
              double* __restrict__ haloR, int haloCap, double* __restrict__ monitor, const int* __restrict__ tileBand,
-             int part) {
+             int part, int bandw) {
   static_assert(!(MON && FUSED), "the force monitor runs with the plain force kernel");
   __shared__ XY txy[kTileCapB];   // (x, y) of the tile; (vx, vy) once the pair loop is done
   __shared__ XY tss[kTileCapB];   // (sx, sy)
   __shared__ double tP[kTileCapB];
 
   const int t = threadIdx.x;
-  const int tile_id = tile_of_block(tiles_expected(w));
+  // part 1 / 2: the blocks with / without band particles only (halo overlap: two launches, the exchange starts
+  // between them); 0: all blocks.  bandw > 0 (slabs of rows: the band blocks are the first and last of the sorted
+  // order): part 1 is a launch of 2 bandw workgroups over the first and the last bandw blocks -- a small kernel
+  // instead of a second pass over the whole grid --, part 2 leaves exactly those band blocks out.  (Running the two
+  // side by side on two streams was measured and dropped: each waits ~8 us for the other stream's event.)
+  int tile_id;
+  if (part == 1 && bandw > 0) {
+    const int nt = (counters[C_NT] + kTileW - 1) / kTileW, b = blockIdx.x;
+    tile_id = b < bandw ? b : nt - 1 - (b - bandw);
+    if (tile_id < 0 || (b >= bandw && tile_id < bandw)) return;  // fewer than 2 bandw blocks: the low end has it
+  } else {
+    tile_id = tile_of_block(tiles_expected(w));
+  }
   const int i0 = tile_id * kTileW;
   const int i = i0 + t;
   SC_STAMP(1, 0);
@@ -943,8 +955,6 @@ __global__ void __launch_bounds__(kTileW)
 #pragma unroll
   for (int s = 0; s < kMaxNbr; ++s) js[s] = nbr16[(size_t)s * cap + ic];
   const int n = counters[C_NT];
-  // part 1 / 2: the blocks with / without band particles only (halo overlap: two launches, the exchange starts
-  // between them); 0: all blocks
   if (tile_id == 0 && t == 0 && part != 2) {
     counters[C_NS] = n;    // the storage arrays now hold the n live particles
     counters[C_SUMC] = 0;  // per-tick counters start the next tick at zero (sc_step_stats reads them
@@ -956,7 +966,11 @@ __global__ void __launch_bounds__(kTileW)
     progress[2] = n;           // ... and sizes heuristics by a recent live count
   }
   if (i0 >= n) return;
-  if (part && (tileBand[tile_id] != 0) != (part == 1)) return;
+  if (part) {
+    const int nt = (n + kTileW - 1) / kTileW;
+    const bool first_launch = tileBand[tile_id] != 0 && (bandw <= 0 || tile_id < bandw || tile_id >= nt - bandw);
+    if (first_launch != (part == 1)) return;
+  }
   SC_STAMP(1, 1);
   const int m = min(kTileW, n - i0);
   const bool live = t < m;
@@ -1070,7 +1084,7 @@ __global__ void __launch_bounds__(kTileW)
     // slabs: the coming tick's halo message is packed here too (same rule and same pre-wall-fix position as
     // k_halo_pack); a workgroup-uniform branch, every lane of the wave takes part
     if (wn.slab && haloL)
-      halo_pack_one(active, xp, yp, vxn, vyn, idn, wn.d, w.own_lo, w.own_hi, w.halo, w.has_left, w.has_right, haloL,
+      halo_pack_one(active, xp, yp, vxn, vyn, idn, wn.d, wn.slab_axis, w.own_lo, w.own_hi, w.halo, w.has_left, w.has_right, haloL,
                     haloR, haloCap, counters, part == 2);
   }
   SC_STAMP(1, 6);

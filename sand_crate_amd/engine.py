@@ -219,6 +219,10 @@ class Engine:
     def set_slab(self, col_lo: int, col_hi: int, halo: int, has_left: bool, has_right: bool) -> None:
         N.check(self._lib.sc_set_slab(self._ctx, int(col_lo), int(col_hi), int(halo), int(has_left), int(has_right)))
 
+    def set_slab_axis(self, axis: int) -> None:
+        """0: slabs are ranges of columns floor(x / d) (the default); 1: of rows floor(y / d)."""
+        N.check(self._lib.sc_set_slab_axis(self._ctx, int(axis)))
+
     def halo_pack(self, dev_left: int, dev_right: int, capacity_records: int) -> None:
         N.check(self._lib.sc_halo_pack(self._ctx, N._P(dev_left), N._P(dev_right), int(capacity_records)))
 

@@ -1,11 +1,15 @@
-"""Multi-GPU: the particle update sharded into x-slabs, one process per GPU, ghost particles
+"""Multi-GPU: the particle update sharded into slabs, one process per GPU, ghost particles
 exchanged with the two neighbor ranks every tick (the reference has no
 multi-device code, so this is new design, checked against the single-domain result).
 
 Decomposition
-    column = floor(x / diameter) of a particle's position at the start of the tick.  Rank k owns the
-    columns [lo_k, hi_k); cuts are chosen once from the initial column histogram so that every rank
-    starts with about the same number of particles.
+    column = floor(x / diameter) of a particle's position at the start of the tick (`axis="x"`), or its row
+    floor(y / diameter) (`axis="y"`).  Rank k owns the columns / rows [lo_k, hi_k); cuts are chosen once from the
+    initial histogram so that every rank starts with about the same number of particles.  Results do not depend on
+    the axis.  Columns keep the ranks balanced when the particles settle under gravity; rows make the halo bands
+    the first and last blocks of the (row-major) sorted order, so that the halo overlap costs almost nothing
+    (with columns a third of the force kernel's blocks hold band particles and its split into two launches costs
+    ~25 us per tick at a million particles; bench.py uses rows: its window is the uniform start of the workload).
 Ghost band
     3 columns on each side.  Interaction range is one diameter after the hard wall fix, which moves
     a particle by at most 0.1 d per wall contact, and pass B needs pressure and surface normal of
@@ -148,6 +152,9 @@ class HipSlabBackend:
     def load(self, particles, velocities, ids) -> None:
         self.engine.upload_with_ids(particles, velocities, ids)
 
+    def set_axis(self, axis: int) -> None:
+        self.engine.set_slab_axis(axis)
+
     def set_slab(self, lo, hi, halo, has_left, has_right) -> None:
         self.engine.set_slab(lo, hi, halo, has_left, has_right)
 
@@ -226,7 +233,7 @@ class SlabCrate:
                  noise_seed: int = 0, group=None, backend=None, halo_capacity: int | None = None,
                  capacity: int | None = None, transport: str | None = None, rebalance_every: int = 0,
                  cuts: list[int] | None = None, overlap: bool = True, rank: int | None = None,
-                 world: int | None = None):
+                 world: int | None = None, axis: str = "x"):
         """`rank` / `world` given: a member of an in-process `SlabChain` (the chain moves the messages and adds the
         histograms); otherwise they come from torch.distributed."""
         import torch.distributed as dist
@@ -255,7 +262,10 @@ class SlabCrate:
         p = np.ascontiguousarray(particles, dtype=np.float64).reshape(-1, 2)
         v = np.ascontiguousarray(velocities, dtype=np.float64).reshape(-1, 2)
         d = self.particle_radius * 2
-        cols = column_of(p[:, 0], d)
+        if axis not in ("x", "y"):
+            raise ValueError("axis must be 'x' (slabs of columns) or 'y' (slabs of rows)")
+        self.axis = axis
+        cols = column_of(p[:, 1 if axis == "y" else 0], d)
         self.slabs = partition_columns(cols, self.world)
         if cuts is not None:  # the caller's cut columns instead of the equal-count ones
             if len(cuts) != self.world - 1 or any(b - a < 2 * HALO_COLUMNS + 2 for a, b in zip(cuts[:-1], cuts[1:])):
@@ -276,6 +286,8 @@ class SlabCrate:
         self.left = self.rank - 1 if self.rank > 0 else None
         self.right = self.rank + 1 if self.rank < self.world - 1 else None
         self.backend = backend if backend is not None else HipSlabBackend(capacity, halo_capacity, device, noise, noise_seed)
+        if axis == "y" or hasattr(self.backend, "set_axis"):
+            self.backend.set_axis(1 if axis == "y" else 0)
         self.backend.set_slab(self.lo, self.hi, HALO_COLUMNS, self.left is not None, self.right is not None)
         self._own_mask = own
         self.backend.load(p[own], v[own], ids)
@@ -556,14 +568,15 @@ class SlabChain:
 
     def __init__(self, world_config, particles, velocities, n_slabs: int, *, device: int = 0, noise: str = "counter",
                  noise_seed: int = 0, halo_capacity: int | None = None, capacity: int | None = None,
-                 rebalance_every: int = 0, cuts: list[int] | None = None, overlap: bool = True, backend_factory=None):
+                 rebalance_every: int = 0, cuts: list[int] | None = None, overlap: bool = True, backend_factory=None,
+                 axis: str = "x"):
         self.members = []
         for k in range(n_slabs):
             backend = backend_factory(k) if backend_factory is not None else None
             self.members.append(SlabCrate(copy.deepcopy(world_config), particles, velocities, device=device, noise=noise,
                                           noise_seed=noise_seed, halo_capacity=halo_capacity, capacity=capacity,
                                           rebalance_every=rebalance_every, cuts=cuts, overlap=overlap, rank=k,
-                                          world=n_slabs, backend=backend))
+                                          world=n_slabs, backend=backend, axis=axis))
         self.tick = 0
         self.message_records = []  # per tick: the records every message carried (left-to-right, then right-to-left)
 

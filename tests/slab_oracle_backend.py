@@ -26,6 +26,9 @@ class OracleSlabBackend:
         self.p, self.v, self.ids = particles.copy(), velocities.copy(), ids.copy()
         self.pressure = np.zeros(len(ids))
 
+    def set_axis(self, axis):
+        self.axis = int(axis)
+
     def set_slab(self, lo, hi, halo, has_left, has_right):
         self.lo, self.hi, self.halo, self.has_left, self.has_right = lo, hi, halo, has_left, has_right
 
@@ -43,7 +46,7 @@ class OracleSlabBackend:
         tensor.copy_(torch.from_numpy(buf.reshape(-1)))
 
     def pack(self):
-        col = column_of(self.p[:, 0], 2 * self.coef["particle_radius"])
+        col = column_of(self.p[:, self.axis], 2 * self.coef["particle_radius"])
         self._fill(self.send_left, (col < self.lo + self.halo) if self.has_left else np.zeros(len(col), bool))
         self._fill(self.send_right, (col >= self.hi - self.halo) if self.has_right else np.zeros(len(col), bool))
 
@@ -51,7 +54,7 @@ class OracleSlabBackend:
         return (self.cap,) * 4  # the lagged sizes are the library's business (sc_halo_sizes); here: whole buffers
 
     def column_histogram(self, col0, n_columns):
-        col = column_of(self.p[:, 0], 2 * self.coef["particle_radius"])
+        col = column_of(self.p[:, self.axis], 2 * self.coef["particle_radius"])
         return np.bincount(np.clip(col - col0, 0, n_columns - 1), minlength=n_columns).astype(np.int64)
 
     def unpack(self, from_left, from_right, sizes=None):
@@ -68,7 +71,7 @@ class OracleSlabBackend:
     def step(self, next_inputs=None):  # no look-ahead here: SlabCrate packs explicitly every tick
         c = self.coef
         p, v, ids = remove_outside(self.p, self.v, c["particle_radius"], self.ids)
-        col = column_of(p[:, 0], 2 * c["particle_radius"])
+        col = column_of(p[:, self.axis], 2 * c["particle_radius"])
         own = (col >= self.lo) & (col < self.hi)
         keep = own | ((col >= self.lo - self.halo) & (col < self.hi + self.halo))
         p, v, ids, own = p[keep], v[keep], ids[keep], own[keep]

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--halo-capacity", type=int, default=0, help="records per halo message (0 = SlabCrate's default)")
     ap.add_argument("--rebalance-every", type=int, default=0)
     ap.add_argument("--skew", type=float, default=1.0, help="x -> x ** skew: more particles on the left")
+    ap.add_argument("--axis", default="x", choices=["x", "y"], help="slabs of columns (x) or of rows (y)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     import torch.distributed as dist
@@ -51,7 +52,7 @@ def main():
         from slab_oracle_backend import OracleSlabBackend
         backend = OracleSlabBackend(halo_capacity=a.particles, noise=a.noise, noise_seed=9)
     sim = SlabCrate(wc, p, v, device=0, noise=a.noise, noise_seed=9, backend=backend,
-                    halo_capacity=a.halo_capacity or None, rebalance_every=a.rebalance_every)
+                    halo_capacity=a.halo_capacity or None, rebalance_every=a.rebalance_every, axis=a.axis)
     first_cuts = list(sim.slabs)
     if a.mixed:
         sim.run(2)

@@ -267,3 +267,35 @@ def test_slabs_in_a_pile_up_state_equal_the_single_domain(sc, overlap):
     chain.synchronize()
     assert sum(chain.owned_counts()) == len(single[3])
     assert_chain_equals_single(chain, single)
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_row_slabs_equal_the_single_domain(sc, overlap):
+    """Slabs of rows (axis="y"): ghosts, migration, halo overlap and the look-ahead packing decided by floor(y / d);
+    the uniform workload with its motored wall, and the pile-up state."""
+    from sand_crate_amd.slab import SlabChain
+    from test_gpu_parity import wave_world
+    from test_gpu_round2 import pile_up_state
+    n, ticks = 300000, 6
+    wc, p, v, d = bench_world(n)
+    single, _ = single_domain(sc, wc, p, v, ticks)
+    chain = SlabChain(copy.deepcopy(wc), p, v, 3, noise="counter", noise_seed=1, overlap=overlap, axis="y")
+    chain.run(ticks)
+    chain.synchronize()
+    assert min(chain.owned_counts()) > 0.8 * n / 3
+    assert_chain_equals_single(chain, single)
+    rows = np.floor(p[:, 1] / d).astype(np.int64)
+    assert chain.slabs[0][1] == chain.slabs[1][0] and (rows < chain.slabs[0][1]).sum() > 0.3 * n  # cut by rows
+    del chain
+    d2, ticks = 0.012, 4
+    p, v = pile_up_state(d2)
+    wc = wave_world(sc, d2, 0.1)
+    wc.coefficients["max_particles"] = len(p)
+    single, _ = single_domain(sc, wc, p, v, ticks)
+    # (no overlap here: the equal-count cuts fall right beside the piles' rows, and what a pile of 3000 in one cell
+    # throws out crosses more rows per tick than an overlapped message allows for -- that is reported, see
+    # test_particle_too_fast_for_the_overlapped_message_is_reported)
+    chain = SlabChain(copy.deepcopy(wc), p, v, 3, noise="counter", noise_seed=1, overlap=False, axis="y")
+    chain.run(ticks)
+    chain.synchronize()
+    assert_chain_equals_single(chain, single)

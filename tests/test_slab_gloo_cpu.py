@@ -65,6 +65,21 @@ def test_slabs_equal_single_domain(tmp_path, nproc, noise, vel, margin, n):
     assert np.array_equal(got["pressure"], pr)
 
 
+@pytest.mark.parametrize("nproc,n,extra", [(3, 3000, ()), (8, 24000, ("--rebalance-every", "2"))])
+def test_row_slabs_equal_single_domain(tmp_path, nproc, n, extra):
+    """The same with the domain cut into slabs of ROWS (axis="y": the halo bands are then the first and last blocks
+    of the row-major sorted order); 8 ranks also re-derive their cuts from the row histogram on the way."""
+    ticks, vel, margin = 5, 30.0, 0.0
+    got = run_workers(nproc, tmp_path / "slab.npz", "--backend", "oracle", "--particles", str(n), "--ticks", str(ticks),
+                      "--vel", str(vel), "--noise", "counter", "--margin", str(margin), "--axis", "y", *extra)
+    p, v, pr, ids = single_domain_oracle(n, ticks, vel, "counter", margin)
+    assert int(got["count"]) == len(ids)
+    assert np.array_equal(got["ids"], ids)
+    assert np.array_equal(got["particles"], p)
+    assert np.array_equal(got["velocities"], v)
+    assert np.array_equal(got["pressure"], pr)
+
+
 @pytest.mark.parametrize("nproc,n", [(2, 4000), (8, 24000)])
 def test_rebalanced_slabs_equal_single_domain(tmp_path, nproc, n):
     """Cuts re-derived from the global column histogram every 2 ticks (one all-reduce), on a domain whose particles
