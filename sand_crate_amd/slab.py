@@ -232,7 +232,7 @@ class SlabCrate:
     def __init__(self, world_config, particles, velocities, *, device: int = 0, noise: str = "counter",
                  noise_seed: int = 0, group=None, backend=None, halo_capacity: int | None = None,
                  capacity: int | None = None, transport: str | None = None, rebalance_every: int = 0,
-                 cuts: list[int] | None = None, overlap: bool = True, rank: int | None = None,
+                 cuts: list[int] | None = None, overlap: bool | None = None, rank: int | None = None,
                  world: int | None = None, axis: str = "x"):
         """`rank` / `world` given: a member of an in-process `SlabChain` (the chain moves the messages and adds the
         histograms); otherwise they come from torch.distributed."""
@@ -292,6 +292,8 @@ class SlabCrate:
         self._own_mask = own
         self.backend.load(p[own], v[own], ids)
         self.halo_capacity = int(halo_capacity)
+        if overlap is None:  # by default only where a particle may cross many cells per tick and still be packed in time
+            overlap = axis == "y"
         self.overlap = bool(overlap) and self.world > 1 and hasattr(self.backend, "set_overlap")
         if self.overlap:
             self.backend.set_overlap(True)
@@ -568,8 +570,8 @@ class SlabChain:
 
     def __init__(self, world_config, particles, velocities, n_slabs: int, *, device: int = 0, noise: str = "counter",
                  noise_seed: int = 0, halo_capacity: int | None = None, capacity: int | None = None,
-                 rebalance_every: int = 0, cuts: list[int] | None = None, overlap: bool = True, backend_factory=None,
-                 axis: str = "x"):
+                 rebalance_every: int = 0, cuts: list[int] | None = None, overlap: bool | None = None,
+                 backend_factory=None, axis: str = "x"):
         self.members = []
         for k in range(n_slabs):
             backend = backend_factory(k) if backend_factory is not None else None

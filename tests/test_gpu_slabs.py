@@ -99,7 +99,8 @@ def test_config3_four_slabs_at_4m_equal_single_gpu(sc):
     n, ticks = 4194304, 3
     wc, p, v, d = bench_world(n)
     single, segments = single_domain(sc, wc, p, v, ticks)
-    chain = SlabChain(copy.deepcopy(wc), p, v, 4, noise="counter", noise_seed=1)
+    chain = SlabChain(copy.deepcopy(wc), p, v, 4, noise="counter", noise_seed=1, axis="y")  # as bench.py cuts it
+    assert all(m.overlap for m in chain.members)
     chain.run(ticks)
     chain.synchronize()
     assert sum(chain.owned_counts()) == len(single[3]) == n
@@ -118,7 +119,8 @@ def test_config4_eight_slabs_at_16m_with_the_motored_wall(sc):
     wc, p, v, d = bench_world(n)
     assert any("motored" in body for body in wc.rigid_bodies)
     single, segments = single_domain(sc, wc, p, v, ticks)
-    chain = SlabChain(copy.deepcopy(wc), p, v, 8, noise="counter", noise_seed=1)
+    chain = SlabChain(copy.deepcopy(wc), p, v, 8, noise="counter", noise_seed=1, axis="y")  # as bench.py cuts it
+    assert all(m.overlap for m in chain.members)
     chain.run(ticks)
     chain.synchronize()
     counts = chain.owned_counts()
