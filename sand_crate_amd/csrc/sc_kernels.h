@@ -576,6 +576,7 @@ __global__ void __launch_bounds__(kReorderBlock)
   __shared__ int pick;
   const int s = chunk_of_block(live_hint) * blockDim.x + threadIdx.x;
   const int nlive = counters[C_NT];
+  if (s - (int)threadIdx.x >= nlive) return;  // a block beyond the live particles (a slab's grid covers its capacity)
   const bool live = s < nlive;
   int i = 0, idi = 0, cpacked = 0, c = 0, wsi = 0, b = 0, e = 0;
   double xi = 0, yi = 0, vxi = 0, vyi = 0;
