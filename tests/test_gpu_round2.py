@@ -349,3 +349,28 @@ def test_pile_up_ticks_match_the_oracle(sc, noise):
         np.testing.assert_allclose(gv, out["velocities"], rtol=1e-9, atol=1e-10)
         np.testing.assert_allclose(gpr, out["pressure"], rtol=1e-9, atol=1e-12)
         p, v = gp, gv
+
+
+def test_pile_up_tick_does_not_depend_on_the_storage_order(sc, tmp_path):
+    """The contract workload run into its pile-up regime (262,144 particles, tick 240: cells of thousands, particles
+    crossing cells every tick).  A context restored from a checkpoint holds the particles in upload order instead of
+    the running context's storage order, so every order-dependent choice inside the tick differs -- arrival order in
+    the buckets, which are then sorted chunk by chunk, runs of equal cells and the grouping of scrambled waves, the
+    atomics of the cell counts -- and the state after the tick must be the same bit for bit."""
+    import bench
+    n = 262144
+    wc, d = bench.world_for(n)
+    p, v = bench.synthetic_state(n)
+    crate = sc.Crate(copy.deepcopy(wc), noise="counter", noise_seed=1, capacity=n + 1024)
+    crate.particles = p
+    crate.particle_velocities = v
+    crate.run(240)
+    crate.save_checkpoint(tmp_path / "pile.npz")
+    crate.run(1)
+    after = crate.engine.download()
+    cells = np.floor(after[0][:, 1] / d).astype(np.int64) * 100000 + np.floor(after[0][:, 0] / d).astype(np.int64)
+    assert np.unique(cells, return_counts=True)[1].max() > 2048  # buckets of several sorting chunks
+    again = sc.Crate.from_checkpoint(tmp_path / "pile.npz", capacity=n + 1024)
+    again.run(1)
+    for a, b in zip(after, again.engine.download()):
+        assert np.array_equal(a, b, equal_nan=True)
