@@ -334,7 +334,7 @@ def main() -> None:
                                    f"collider noise 0.1 ({args.noise} RNG), ticks {args.warmup}..{args.warmup + args.steps - 1}",
                        "particles_per_gpu": per_gpu, "particles_total": n_total, "live_after_run": int(n_live),
                        "parallelism": "single GPU" if world == 1 else f"{world} slabs of {'rows' if args.slab_axis == 'y' else 'columns'}, halo exchange per tick",
-                       "transport": transport}}
+                       "transport": transport, "halo_overlap": bool(slab_sim[0].overlap) if world > 1 else None}}
     if rank == 0 and args.no_kernel_events:
         base["note"] = "no per-kernel events"
         print(json.dumps(base))
