@@ -374,3 +374,35 @@ def test_pile_up_tick_does_not_depend_on_the_storage_order(sc, tmp_path):
     again.run(1)
     for a, b in zip(after, again.engine.download()):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_tiles_just_over_the_force_kernels_budget_match_the_oracle(sc):
+    """A fluid a third denser than the contract workload: the candidate ranges of most blocks hold 960..1100 entries --
+    staged in LDS by the search (budget 1024 / 1100) but beyond the force kernel's 960 -- so the search renumbers its
+    table to the ranges the lists reach and the force kernel stages those.  Ticks against the oracle."""
+    from oracle.scene import OracleCrate
+    from oracle.tick import counter_noise_key, counter_noise_u01, remove_outside, tick_core
+    from oracle.world import World
+    n = 60000
+    p, v, d = synthetic(n, seed=77, margin=0.02, vel=0.1)
+    d *= 1.16
+    wc = wave_world(sc, d, 0.1)
+    wc.coefficients["max_particles"] = n
+    crate = sc.Crate(wc, noise="counter", noise_seed=5, capacity=n + 64)
+    crate.particles = p
+    crate.particle_velocities = v
+    orc = OracleCrate(World(wc.rigid_bodies, [], dict(wc.coefficients)))
+    ids = np.arange(n)
+    for t in range(2):
+        crate.physics_tick()
+        for b in orc.rigid_bodies:
+            b.advance(orc.coef["dt"])
+        p, v, ids = remove_outside(p, v, orc.coef["particle_radius"], ids)
+        out = tick_core(p, v, orc.segments, orc.body_states(), orc.coef, eta_u01=counter_noise_u01(ids, counter_noise_key(5, t)))
+        gp, gv, gpr, gids = crate.engine.download()
+        assert np.array_equal(gids, ids)
+        assert 15.0 < out["neighbor_counts"].mean() < 18.0
+        np.testing.assert_allclose(gp, out["particles"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(gv, out["velocities"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(gpr, out["pressure"], rtol=1e-9, atol=1e-12)
+        p, v = gp, gv
