@@ -89,6 +89,7 @@ struct sc_ctx {
   hipEvent_t ev_band = nullptr, ev_xchg = nullptr;
   int *cellCount = nullptr, *cellStart = nullptr, *blockSums = nullptr, *blockOff = nullptr, *sortedStamp = nullptr;
   int* bigList = nullptr;
+  int* bigTable = nullptr;  // k_sort_big's task table (start, length, tasks before, per listed bucket): the scan builds it
   RcclComm comm = nullptr;  // RCCL communicator of the slab chain (sc_comm_init), or null
   int comm_rank = -1, comm_world = 0;
   double *haloL = nullptr, *haloR = nullptr;  // send buffers of the last sc_halo_pack (caller-owned device memory)
@@ -575,6 +576,7 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
   if (e == hipSuccess) e = dalloc(&c->tileBand, n / kTileW + 2);
   if (e == hipSuccess) e = hipMemsetAsync(c->tileBand, 0, (n / kTileW + 2) * sizeof(int), c->stream);
   if (e == hipSuccess) e = dalloc(&c->bigList, (size_t)kMaxBig);
+  if (e == hipSuccess) e = dalloc(&c->bigTable, (size_t)kBigTable);
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->bigHintHost, kProgressInts * sizeof(int), hipHostMallocMapped);
   if (e == hipSuccess) {
     for (int k = 0; k < kProgressInts; ++k) c->bigHintHost[k] = 0;
@@ -613,7 +615,7 @@ int sc_destroy(sc_ctx* c) {
   }
   if (c->ev_band) (void)hipEventDestroy(c->ev_band);
   if (c->ev_xchg) (void)hipEventDestroy(c->ev_xchg);
-  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->tileBoundsT, c->tileBand, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->wrec[0], c->wrec[1],
+  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->tileBoundsT, c->tileBand, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->bigTable, c->wrec[0], c->wrec[1],
                   c->nbr, c->nbr16, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
                   c->stage_xy, c->stage_vxy, c->stage_ids, c->owned_out, c->colHist, c->rng, c->monitor,
                   c->snap_d[0], c->snap_d[1], c->snap_d[2], c->snap_d[3], c->snap_id_d, c->snap_rng_d};
@@ -767,7 +769,7 @@ int sc_step_begin(sc_ctx* c) {
     const int64_t ncells = (int64_t)w.nrows * w.ncols;
     const int nb = (int)((ncells + 1 + kScanPerBlock - 1) / kScanPerBlock);  // covers the one-past-the-end entry
     hipLaunchKernelGGL(k_scan_cells, dim3(nb), dim3(kBlock), 0, c->stream, c->cellCount, c->cellStart, (int)ncells,
-                       c->blockSums, c->blockOff, c->counters, c->bigList, c->bigHintDev);
+                       c->blockSums, c->blockOff, c->counters, c->bigList, c->bigHintDev, c->bigTable);
   }
   {
     Bracket br(c, K_SCATTER);
@@ -784,7 +786,7 @@ int sc_step_begin(sc_ctx* c) {
   if (piles_expected(c)) {
     Bracket br(c, K_SCAN);
     hipLaunchKernelGGL(k_sort_big, dim3(4 * c->num_cus), dim3(kSortBlock), 0, c->stream, c->counters, c->bigList,
-                       Buckets{c->cellStart, c->blockOff}, c->keyX, c->keyId, c->perm, c->sortedStamp, stamp);
+                       c->bigTable, c->keyX, c->keyId, c->perm, c->sortedStamp, stamp);
   }
   {
     Bracket br(c, K_REORDER);

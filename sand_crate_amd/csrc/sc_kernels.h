@@ -276,6 +276,10 @@ __global__ void __launch_bounds__(kBlock) k_scan_fix(int* __restrict__ out, int 
 // the cells is needed: every workgroup scans its block, and the last one to finish (ticket) scans
 // the block totals.  Readers add the two (struct Buckets).  Saves a ~5 us launch per tick.
 constexpr int kSortThreshold = 96;  // buckets above this many particles are listed for k_sort_big
+constexpr int kSortBlock = 256;
+constexpr int kSortChunk = 2048;       // slots per sorting task: 32 KB of LDS for (x, id, storage index)
+constexpr int kRankMaxBuckets = 4096;  // big buckets sorted per tick = the room in the list (more: ranked in K4 by counting)
+constexpr int kBigTable = 3 * (kRankMaxBuckets + 1);  // k_sort_big's task table: start, length, tasks before, per bucket
 constexpr int kMaxBig = 4096;       // room in the list of big buckets
 constexpr int kScanShift = 11;
 static_assert((1 << kScanShift) == kScanPerBlock, "block offset lookup assumes 2048 cells per scan block");
@@ -289,7 +293,7 @@ struct Buckets {
 __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ in, int* __restrict__ out, int n,
                                                        int* __restrict__ blockSums, int* __restrict__ blockOff,
                                                        int* __restrict__ counters, int* __restrict__ bigList,
-                                                       volatile int* __restrict__ bigHint) {
+                                                       volatile int* __restrict__ bigHint, int* __restrict__ bigTable) {
   __shared__ int waveTot[kBlock / 64];
   __shared__ int last;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -353,13 +357,47 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
     if (k < nb) blockOff[k] = carry + wbase + incl - e;
     carry += tot;
   }
+  const int nbig_all = __hip_atomic_load(&counters[C_NBIG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x == 0) {
     counters[C_NT] = carry;  // live particles = entries of the sorted arrays
     counters[C_TICKET] = 0;
     // a hint for the host, in host-mapped memory: were there big buckets?  It is read without any
     // synchronisation when the NEXT tick is enqueued and only decides whether k_sort_big is launched.
-    bigHint[0] = __hip_atomic_load(&counters[C_NBIG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bigHint[0] = nbig_all;
   }
+  // k_sort_big's task table, built once here: per listed bucket its start, its length and the sorting tasks before it
+  const int nbig = min(nbig_all, kRankMaxBuckets);
+  if (nbig == 0) return;  // uniform
+  __syncthreads();        // blockOff is complete
+  int running = 0;        // tasks of the buckets before this round's 256
+  for (int q0 = 0; q0 < nbig; q0 += kBlock) {
+    const int q = q0 + threadIdx.x;
+    int t = 0;
+    if (q < nbig) {
+      const int c = __hip_atomic_load(&bigList[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int b = __hip_atomic_load(&out[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + blockOff[c >> kScanShift];
+      const int e = __hip_atomic_load(&out[c + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + blockOff[(c + 1) >> kScanShift];
+      bigTable[q] = b;
+      bigTable[(kRankMaxBuckets + 1) + q] = e - b;
+      t = (e - b + kSortChunk - 1) / kSortChunk;
+    }
+    int incl = t;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    __syncthreads();
+    if (lane == 63) waveTot[wv] = incl;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+    for (int k = 0; k < kBlock / 64; ++k) {
+      if (k < wv) wbase += waveTot[k];
+      tot += waveTot[k];
+    }
+    if (q < nbig) bigTable[2 * (kRankMaxBuckets + 1) + q] = running + wbase + incl - t;
+    running += tot;
+  }
+  if (threadIdx.x == 0) bigTable[2 * (kRankMaxBuckets + 1) + nbig] = running;  // all tasks
 }
 
 // ------------------------------------------------------------------------------------------
@@ -373,58 +411,22 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
 // its chunk plus, for buckets of several chunks, a binary search in each of the other chunks.
 // Launched only when the previous tick saw big buckets; a bucket that is not stamped is ranked inside K4 by counting.
 // ------------------------------------------------------------------------------------------
-constexpr int kSortBlock = 256;
-constexpr int kSortChunk = 2048;       // 32 KB of LDS for (x, id, storage index)
-constexpr int kRankMaxBuckets = 1024;  // big buckets handled per tick (more: the rest is ranked in K4)
 
 __device__ __forceinline__ bool key_less(double xa, int ia, double xb, int ib) { return xa < xb || (xa == xb && ia < ib); }
 
 __global__ void __launch_bounds__(kSortBlock)
-    k_sort_big(const int* __restrict__ counters, const int* __restrict__ bigList, Buckets bk, double* __restrict__ keyX,
-               int* __restrict__ keyId, int* __restrict__ perm, int* __restrict__ sortedStamp, int stamp) {
-  __shared__ int pre[kRankMaxBuckets + 1];  // tasks before bucket q
-  __shared__ int bstart[kRankMaxBuckets], blen[kRankMaxBuckets];
-  __shared__ int waveTot[kSortBlock / 64];
+    k_sort_big(const int* __restrict__ counters, const int* __restrict__ bigList, const int* __restrict__ bigTable,
+               double* __restrict__ keyX, int* __restrict__ keyId, int* __restrict__ perm, int* __restrict__ sortedStamp,
+               int stamp) {
+  __shared__ int pre[kRankMaxBuckets + 1];  // tasks before bucket q (the scan built the table)
   __shared__ double kx[kSortChunk];
   __shared__ int kid[kSortChunk], kpm[kSortChunk];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x;
   const int nbig = min(__hip_atomic_load(&counters[C_NBIG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), kRankMaxBuckets);
   if (nbig == 0) return;
-  // every workgroup derives the same task table from the same list
-  constexpr int kPer = kRankMaxBuckets / kSortBlock;
-  int tasks[kPer], sum = 0;
-#pragma unroll
-  for (int k = 0; k < kPer; ++k) {
-    const int q = tid * kPer + k;
-    int t = 0;
-    if (q < nbig) {
-      const int c = bigList[q];
-      const int b = bk(c), len = bk(c + 1) - b;
-      bstart[q] = b;
-      blen[q] = len;
-      t = (len + kSortChunk - 1) / kSortChunk;
-    }
-    tasks[k] = sum;
-    sum += t;
-  }
-  int incl = sum;
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
-  }
-  if (lane == 63) waveTot[wv] = incl;
+  for (int q = tid; q <= nbig; q += kSortBlock) pre[q] = bigTable[2 * (kRankMaxBuckets + 1) + q];
   __syncthreads();
-  int wbase = 0, total = 0;
-  for (int k = 0; k < kSortBlock / 64; ++k) {
-    if (k < wv) wbase += waveTot[k];
-    total += waveTot[k];
-  }
-#pragma unroll
-  for (int k = 0; k < kPer; ++k) {
-    const int q = tid * kPer + k;
-    if (q <= nbig) pre[q] = wbase + incl - sum + tasks[k];
-  }
-  __syncthreads();
+  const int total = pre[nbig];
   for (int task = blockIdx.x; task < total; task += gridDim.x) {
     int lo = 0, hi = nbig;  // the bucket of this task: last q with pre[q] <= task
     while (hi - lo > 1) {
@@ -432,7 +434,7 @@ __global__ void __launch_bounds__(kSortBlock)
       if (pre[mid] <= task) lo = mid; else hi = mid;
     }
     const int q = lo, local = task - pre[q];
-    const int b = bstart[q] + local * kSortChunk, len = min(kSortChunk, blen[q] - local * kSortChunk);
+    const int b = bigTable[q] + local * kSortChunk, len = min(kSortChunk, bigTable[(kRankMaxBuckets + 1) + q] - local * kSortChunk);
     int n = 64;  // the network's size: the power of two that holds the chunk
     while (n < len) n <<= 1;
     __syncthreads();  // the previous task's write-back has read the arrays

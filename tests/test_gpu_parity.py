@@ -688,15 +688,15 @@ def test_tick_reports_a_bad_promise_and_stays_usable(sc):
 
 
 def test_more_big_buckets_than_the_rank_kernel_lists(sc):
-    """k_sort_big takes the first 1024 big buckets of a tick; the rest is ranked inside the reorder kernel.
-    1150 cells of 100 particles each, with x ties: the sorted order must still be the reference's."""
+    """k_sort_big sorts the first 4096 big buckets of a tick; the rest is ranked inside the reorder kernel by counting.
+    4400 cells of 100 particles each, with x ties: the sorted order must still be the reference's."""
     from oracle.neighbors import strip_sort
     rs = np.random.RandomState(8)
-    d = 0.02
-    cells = rs.permutation(45 * 45)[:1150]
-    cx, cy = (cells % 45 + 2) * d, (cells // 45 + 2) * d
-    pts = np.column_stack(((cx[:, None] + np.round(rs.rand(1150, 100) * 8) / 8 * d * 0.9).ravel(),
-                           (cy[:, None] + rs.rand(1150, 100) * d * 0.99).ravel()))
+    d, side, ncell = 0.01, 90, 4400
+    cells = rs.permutation(side * side)[:ncell]
+    cx, cy = (cells % side + 2) * d, (cells // side + 2) * d
+    pts = np.column_stack(((cx[:, None] + np.round(rs.rand(ncell, 100) * 8) / 8 * d * 0.9).ravel(),
+                           (cy[:, None] + rs.rand(ncell, 100) * d * 0.99).ravel()))
     pts = pts[rs.permutation(len(pts))]
     rows, order, counts, table = sc.neighbor_search(pts, d)
     ref_rows, ref_order = strip_sort(pts, d)
