@@ -239,6 +239,39 @@ def main() -> None:
             return None
 
     slab_sim = []
+    band_mode = {}
+
+    def pick_band_mode(sim):
+        """Halo overlap with slabs of rows: the force kernel either runs as two launches with an event in between or as
+        one launch whose band blocks release the side stream through a flag that a one-thread kernel polls
+        (sc_set_band_flag: cheaper, unless the side stream shares a hardware queue with the context's stream -- then every
+        tick costs the poll's time-out).  Both are timed here on a few untimed ticks and the faster one is kept; all ranks
+        take the same decision (the slowest rank's time counts)."""
+        if not (sim.overlap and sim.axis == "y"):
+            return
+        from sand_crate_amd._native import NativeError
+        took = {}
+        for flag in (True, False):
+            sim.reload(p, v)
+            seconds = float("inf")
+            try:
+                if sim.set_band_flag(flag) == flag:
+                    sim.run(3)
+                    sim.synchronize()
+                    barrier()
+                    t0 = time.perf_counter()
+                    sim.run(8)
+                    sim.synchronize()
+                    seconds = time.perf_counter() - t0
+            except NativeError:
+                pass
+            t = torch.tensor([min(seconds, 1e9)], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            took[flag] = float(t.item())
+        sim.reload(p, v)
+        sim.set_band_flag(took[True] < took[False])
+        band_mode.update({"one launch + flag": round(1e3 * took[True] / 8, 4), "two launches": round(1e3 * took[False] / 8, 4),
+                          "kept": "one launch + flag" if sim.band_flag else "two launches"})
 
     def make_sim():
         import copy
@@ -248,6 +281,7 @@ def main() -> None:
                 slab_sim[0].reload(p, v)
             else:
                 slab_sim.append(SlabCrate(w, p, v, device=local_rank, noise=args.noise, noise_seed=1, axis=args.slab_axis))
+                pick_band_mode(slab_sim[0])
             return slab_sim[0]
         s = sc.Crate(w, device=local_rank, noise=args.noise, noise_seed=1, capacity=n_total + 1024)
         s.particles = p
@@ -334,7 +368,8 @@ def main() -> None:
                                    f"collider noise 0.1 ({args.noise} RNG), ticks {args.warmup}..{args.warmup + args.steps - 1}",
                        "particles_per_gpu": per_gpu, "particles_total": n_total, "live_after_run": int(n_live),
                        "parallelism": "single GPU" if world == 1 else f"{world} slabs of {'rows' if args.slab_axis == 'y' else 'columns'}, halo exchange per tick",
-                       "transport": transport, "halo_overlap": bool(slab_sim[0].overlap) if world > 1 else None}}
+                       "transport": transport, "halo_overlap": bool(slab_sim[0].overlap) if world > 1 else None,
+                       "halo_overlap_band_mode_ms_per_tick": band_mode or None}}
     if rank == 0 and args.no_kernel_events:
         base["note"] = "no per-kernel events"
         print(json.dumps(base))

@@ -304,9 +304,18 @@ int sc_emit_particles(sc_ctx* ctx, const sc_source* sources, int32_t n_sources, 
  *                           (`peer`, optional: and for what that context's message depends on -- in-process chains);
  *                           the caller then enqueues its copies / sends on sc_side_stream;
  *   sc_halo_overlap_end     the context's stream waits for the side stream; sc_halo_unpack follows as usual.
- * A particle of an interior block that ends the tick inside a band after all (it moved more than two columns) is
- * not silently lost: SC_ERR_DOMAIN at the next synchronising call. */
+ * A particle of an interior block that ends the tick inside a band after all (it moved more than the margin: two
+ * columns / eight rows) is not silently lost: SC_ERR_DOMAIN at the next synchronising call.
+ *
+ * sc_set_band_flag (slabs of rows only): instead of two launches the force kernel runs as ONE whose first workgroups
+ * take the blocks at both ends of the sorted order (where the band blocks are); the last of them to finish publishes
+ * a flag, and the side stream waits for it with a one-thread polling kernel (hipStreamWaitValue32 is not usable
+ * here).  Costs ~4 us per tick instead of ~24 -- PROVIDED the side stream has a hardware queue of its own: a process
+ * with more streams than hardware queues may put the polling kernel in front of the very kernel it waits for, which
+ * then costs the poll's time-out (50 ms, reported as SC_ERR_HIP).  Off by default; bench.py tries it and keeps it when
+ * it is faster. */
 int sc_set_halo_overlap(sc_ctx* ctx, int on);
+int sc_set_band_flag(sc_ctx* ctx, int on);
 int sc_side_stream(sc_ctx* ctx, void** hip_stream);
 int sc_halo_overlap_begin(sc_ctx* ctx, sc_ctx* peer);
 int sc_halo_overlap_end(sc_ctx* ctx);

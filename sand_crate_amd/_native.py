@@ -92,6 +92,7 @@ SIGNATURES = {
     "sc_kernel_name": (C.c_char_p, [C.c_int]),
     "sc_set_slab": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "sc_set_slab_axis": (C.c_int, [_P, C.c_int32]),
+    "sc_set_band_flag": (C.c_int, [_P, C.c_int]),
     "sc_upload_state_ids": (C.c_int, [_P, _D, _D, _I64, C.c_int64]),
     "sc_halo_pack": (C.c_int, [_P, _P, _P, C.c_int64]),
     "sc_halo_sizes": (C.c_int, [_P, C.c_int64, _I64, _I64, _I64, _I64]),

@@ -86,6 +86,9 @@ struct sc_ctx {
   int* tileBand = nullptr;  // per block of pass A / B: holds a particle that may be packed into a halo message
   // halo overlap (sc_set_halo_overlap): the exchange runs on the side stream between the two launches of pass B
   bool overlap = false, band_pending = false;
+  bool band_by_flag = false;  // slabs of rows: the split force kernel is ONE launch + a polling kernel on the side stream (sc_set_band_flag)
+  bool band_flagged = false;  // the pending band is announced by the flag (k_wait_band), not by ev_band
+  int band_epoch = 0;
   hipEvent_t ev_band = nullptr, ev_xchg = nullptr;
   int *cellCount = nullptr, *cellStart = nullptr, *blockSums = nullptr, *blockOff = nullptr, *sortedStamp = nullptr;
   int* bigList = nullptr;
@@ -397,6 +400,8 @@ int check_flags(int flags) {
   if (flags & F_OUT_OF_GRID) return fail(SC_ERR_DOMAIN, "a particle left the cell grid; it was dropped");
   if (flags & F_HALO_OVERFLOW) return fail(SC_ERR_CAPACITY, "a halo buffer was too small; ghost particles were lost");
   if (flags & F_CAPACITY) return fail(SC_ERR_CAPACITY, "received halo particles exceed the context capacity");
+  if (flags & F_BAND_TIMEOUT)
+    return fail(SC_ERR_HIP, "the halo exchange waited 50 ms for the band blocks of the force kernel and gave up");
   if (flags & F_HALO_LATE)
     return fail(SC_ERR_DOMAIN, "a particle moved more than the band margin (%d columns / %d rows) in one tick and missed the "
                 "overlapped halo message: run without halo overlap", kBandMarginColumns, kBandMarginRows);
@@ -497,20 +502,27 @@ void launch_pass_b(sc_ctx* c, const WallInputs& wn, int part = 0) {
     const int64_t band_rows = 2 * c->halo + kBandMarginRows + 2;
     bandw = (int)std::min<int64_t>(tile_grid(c), 2 * band_rows * (c->w.live_hint / rows + 1) / kTileW + 16);
   }
-  const int grid = part == 1 && bandw ? 2 * bandw : tile_grid(c);
+  const int grid = part == 1 && bandw ? 2 * bandw : part == 3 ? tile_grid(c) + 2 * bandw : tile_grid(c);
   hipStream_t stream = c->stream;
   auto launch = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kTileW), 0, stream, c->w, c->counters, c->x[1], c->y[1], c->vx[1],
                        c->vy[1], c->id[1], c->wslotT, c->cellT, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta, c->offById, c->P,
                        c->sx, c->sy, c->wrec[cur], c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], c->tileBoundsT,
                        c->bigHintDev, wn, c->cellS, c->wslotS, c->cellCount, c->wrec[nxt], c->haloL, c->haloR, c->haloCap,
-                       c->monitor, c->tileBand, part, bandw);
+                       c->monitor, c->tileBand, part, bandw, c->band_epoch);
   };
   auto pick = [&]() {
-    if (FUSED && piles_expected(c))
+    const bool group = FUSED && piles_expected(c);
+    if (FUSED && bandw > 0) {  // the instantiation with the band window (slabs of rows, halo overlap)
+      if (group)
+        launch(k_pass_b<NOISE, FUSED, MON, FUSED, FUSED>);
+      else
+        launch(k_pass_b<NOISE, FUSED, MON, false, FUSED>);
+    } else if (group) {
       launch(k_pass_b<NOISE, FUSED, MON, FUSED>);
-    else
+    } else {
       launch(k_pass_b<NOISE, FUSED, MON, false>);
+    }
   };
   Bracket br(c, K_FORCE);
   pick();
@@ -523,10 +535,18 @@ void launch_pass_b_any(sc_ctx* c, bool fused, const WallInputs& wn) {
   } else if (fused && c->slab && c->overlap && c->haloL && (c->has_left || c->has_right)) {
     // halo overlap: the blocks that may pack halo records first; once they are done (ev_band) the exchange of the
     // coming tick may start on the side stream while the interior blocks run
-    launch_pass_b<NOISE, true>(c, wn, 1);
-    (void)hipEventRecord(c->ev_band, c->stream);
+    if (c->slab_axis == 1 && c->band_by_flag) {
+      // slabs of rows: one launch, the window blocks first; the side stream polls for their completion (k_wait_band)
+      c->band_epoch += 1;
+      launch_pass_b<NOISE, true>(c, wn, 3);
+      c->band_flagged = true;
+    } else {
+      launch_pass_b<NOISE, true>(c, wn, 1);
+      (void)hipEventRecord(c->ev_band, c->stream);
+      launch_pass_b<NOISE, true>(c, wn, 2);
+      c->band_flagged = false;
+    }
     c->band_pending = true;
-    launch_pass_b<NOISE, true>(c, wn, 2);
   } else if (fused)
     launch_pass_b<NOISE, true>(c, wn);
   else
@@ -590,8 +610,8 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
   if (e == hipSuccess) e = dalloc(&c->P, n);
   if (e == hipSuccess) e = dalloc(&c->sx, n);
   if (e == hipSuccess) e = dalloc(&c->sy, n);
-  if (e == hipSuccess) e = dalloc(&c->counters, (size_t)C_COUNT);
-  if (e == hipSuccess) e = hipMemsetAsync(c->counters, 0, C_COUNT * sizeof(int), c->stream);
+  if (e == hipSuccess) e = dalloc(&c->counters, (size_t)C_ALLOC);
+  if (e == hipSuccess) e = hipMemsetAsync(c->counters, 0, C_ALLOC * sizeof(int), c->stream);
   if (e != hipSuccess) {
     int rc = fail(SC_ERR_HIP, "sc_create: %s", hipGetErrorString(e));
     sc_destroy(c);
@@ -1382,6 +1402,14 @@ int sc_set_halo_overlap(sc_ctx* c, int on) {
   return SC_OK;
 }
 
+int sc_set_band_flag(sc_ctx* c, int on) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  if (c->in_step) return fail(SC_ERR_STATE, "the band mode cannot change inside a tick");
+  if (c->band_pending) return fail(SC_ERR_STATE, "a halo message is under way");
+  c->band_by_flag = on != 0;
+  return SC_OK;
+}
+
 int sc_side_stream(sc_ctx* c, void** stream) {
   if (!c || !stream) return fail(SC_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(c->device));
@@ -1401,6 +1429,10 @@ int sc_halo_overlap_begin(sc_ctx* c, sc_ctx* peer) {
   for (sc_ctx* q : {c, peer}) {
     if (!q) continue;
     if (q != c && (rc = ensure_side_stream(q))) return rc;
+    if (q->band_pending && q->band_flagged) {  // the window blocks of q's one-launch force kernel
+      hipLaunchKernelGGL(k_wait_band, dim3(1), dim3(1), 0, c->side_stream, q->counters, q->band_epoch);
+      continue;
+    }
     if (!q->band_pending) HIPCHK(hipEventRecord(q->ev_band, q->stream));  // no split pass B before: wait for all of it
     HIPCHK(hipStreamWaitEvent(c->side_stream, q->ev_band, 0));
   }

@@ -92,10 +92,14 @@ enum Counter {
   C_TICKET = 9,  // workgroups that have finished the current halo kernel (last one publishes / bumps)
   C_NBIG = 10,   // buckets above kSortThreshold listed this tick
   C_SPARE11 = 11,
-  C_COUNT = 12
+  C_COUNT = 12,
+  // on cache lines of their own, away from the counters every workgroup reads (k_wait_band polls the flag):
+  C_BAND_DONE = 32,  // halo overlap in one launch: the window blocks of the force kernel that have finished
+  C_BAND_FLAG = 64,  // ... and the epoch of the launch whose window blocks are all done
+  C_ALLOC = 96
 };
 
-enum Flag { F_OUT_OF_GRID = 1, F_NAN = 2, F_HALO_OVERFLOW = 4, F_CAPACITY = 8, F_HALO_LATE = 16 };
+enum Flag { F_OUT_OF_GRID = 1, F_NAN = 2, F_HALO_OVERFLOW = 4, F_CAPACITY = 8, F_HALO_LATE = 16, F_BAND_TIMEOUT = 32 };
 
 // columns / rows a particle may move in one tick and still be packed in time (halo overlap).  With slabs of rows the
 // band blocks are few whatever the margin; with columns every row has them, and each column of margin adds as many.

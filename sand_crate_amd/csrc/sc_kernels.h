@@ -797,7 +797,8 @@ __device__ __forceinline__ int halo_slot(bool want, double* __restrict__ buf) {
 // `d`, own_lo .. has_right: the slab of the COMING tick.  `on`: this lane holds a stored, live particle.
 // `late`: the message has already left (halo overlap: this is an interior tile); a particle that belongs in it
 // after all moved further than the band margin allows -- flagged, never silently dropped.
-__device__ __forceinline__ void halo_pack_one(bool on, double px, double py, double pvx, double pvy, int pid, double d,
+// -> this lane wrote a record
+__device__ __forceinline__ bool halo_pack_one(bool on, double px, double py, double pvx, double pvy, int pid, double d,
                                               int axis, long long own_lo, long long own_hi, int halo, int has_left,
                                               int has_right, double* __restrict__ left, double* __restrict__ right,
                                               int cap, int* __restrict__ counters, bool late = false) {
@@ -809,7 +810,7 @@ __device__ __forceinline__ void halo_pack_one(bool on, double px, double py, dou
   }
   if (late) {
     if (toL || toR) atomicOr(&counters[C_FLAGS], F_HALO_LATE);
-    return;
+    return false;
   }
   const int kl = halo_slot(toL, left), kr = halo_slot(toR, right);
   if (kl >= cap || kr >= cap) atomicOr(&counters[C_FLAGS], F_HALO_OVERFLOW);
@@ -821,6 +822,7 @@ __device__ __forceinline__ void halo_pack_one(bool on, double px, double py, dou
     double* r = right + (size_t)kHaloFields * (kr + 1);
     r[0] = px; r[1] = py; r[2] = pvx; r[3] = pvy; r[4] = (double)pid;
   }
+  return toL || toR;
 }
 
 __global__ void __launch_bounds__(kBlock)

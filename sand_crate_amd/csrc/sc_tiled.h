@@ -905,7 +905,9 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
 // next tick's walls `wn` (sc_set_next_inputs).  That tick then starts at the bucket scan: one launch
 // and one read+write of the positions less per tick.
 // GROUP: the fused cell count groups scrambled waves by cell (sc_kernels.h: count_cells); launched while big buckets exist
-template <int NOISE, bool FUSED, bool MON = false, bool GROUP = false>
+// BANDED: the instantiation the halo overlap launches with slabs of rows (a window of band blocks, parts 1 and 3 below);
+// kept out of the default kernel, where its branches cost 0.8 us per tick in scalar registers
+template <int NOISE, bool FUSED, bool MON = false, bool GROUP = false, bool BANDED = false>
 __global__ void __launch_bounds__(kTileW)
     k_pass_b(World w, int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
              const double* __restrict__ vx, const double* __restrict__ vy, const int* __restrict__ id,
@@ -919,7 +921,7 @@ __global__ void __launch_bounds__(kTileW)
              WallInputs wn, int* __restrict__ cellS, int* __restrict__ wslotS, int* __restrict__ cellCount,
              double* __restrict__ wrec_next, double* __restrict__ haloL,
              double* __restrict__ haloR, int haloCap, double* __restrict__ monitor, const int* __restrict__ tileBand,
-             int part, int bandw) {
+             int part, int bandw, int epoch) {
   static_assert(!(MON && FUSED), "the force monitor runs with the plain force kernel");
   __shared__ XY txy[kTileCapB];   // (x, y) of the tile; (vx, vy) once the pair loop is done
   __shared__ XY tss[kTileCapB];   // (sx, sy)
@@ -931,11 +933,32 @@ __global__ void __launch_bounds__(kTileW)
   // order): part 1 is a launch of 2 bandw workgroups over the first and the last bandw blocks -- a small kernel
   // instead of a second pass over the whole grid --, part 2 leaves exactly those band blocks out.  (Running the two
   // side by side on two streams was measured and dropped: each waits ~8 us for the other stream's event.)
+  // part 3 (slabs of rows again): ONE launch.  Its first 2 bandw workgroups take the window blocks, the others the
+  // blocks in between (placed by XCD as usual); every window block counts itself done, and the one that completes the
+  // count publishes the launch's epoch -- k_wait_band, a one-thread kernel on the side stream, polls for it and lets
+  // the exchange go while the blocks in between are still computing.  No second launch, no event between kernels.
   int tile_id;
-  if (part == 1 && bandw > 0) {
-    const int nt = (counters[C_NT] + kTileW - 1) / kTileW, b = blockIdx.x;
-    tile_id = b < bandw ? b : nt - 1 - (b - bandw);
-    if (tile_id < 0 || (b >= bandw && tile_id < bandw)) return;  // fewer than 2 bandw blocks: the low end has it
+  bool window_block = false, between = false;
+  if (BANDED && (part == 1 || part == 3) && bandw > 0) {
+    const int b = blockIdx.x;
+    if (b < bandw) {  // the low window
+      tile_id = b;
+      window_block = part == 3;
+    } else if (b < 2 * bandw) {  // the high window: only these blocks have to wait for the live count before anything else
+      const int nt = (counters[C_NT] + kTileW - 1) / kTileW;
+      tile_id = nt - 1 - (b - bandw);
+      if (tile_id < bandw) return;  // fewer than 2 bandw blocks: the low window has them
+      window_block = part == 3;
+    } else {  // part 3: the blocks between the windows, bandw .. nt - bandw - 1 (checked once the count is here)
+      const int nb = min((int)gridDim.x - 2 * bandw, max(tiles_expected(w) - 2 * bandw, 0)), ib = b - 2 * bandw;
+      int k = ib;
+      if (ib < nb) {
+        const int q = nb >> 3, r = nb & 7, xcd = ib & 7;
+        k = xcd * q + min(xcd, r) + (ib >> 3);
+      }
+      tile_id = bandw + k;
+      between = true;
+    }
   } else {
     tile_id = tile_of_block(tiles_expected(w));
   }
@@ -965,11 +988,17 @@ __global__ void __launch_bounds__(kTileW)
     progress[1] = w.tick + 1;  // host-mapped: the host keeps at most a few ticks of launches queued
     progress[2] = n;           // ... and sizes heuristics by a recent live count
   }
+  if (BANDED && part == 3 && n == 0 && blockIdx.x == 0 && t == 0)  // nothing at all: nobody else would publish the epoch
+    __hip_atomic_store(&counters[C_BAND_FLAG], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (i0 >= n) return;
-  if (part) {
+  if (BANDED && between && tile_id >= (n + kTileW - 1) / kTileW - bandw) return;  // that block belongs to the high window
+  bool late_block = part == 2;  // this block's halo records (if any) come too late for the message
+  if (part == 1 || part == 2) {
     const int nt = (n + kTileW - 1) / kTileW;
     const bool first_launch = tileBand[tile_id] != 0 && (bandw <= 0 || tile_id < bandw || tile_id >= nt - bandw);
     if (first_launch != (part == 1)) return;
+  } else if (BANDED && part == 3) {
+    late_block = !window_block;
   }
   SC_STAMP(1, 1);
   const int m = min(kTileW, n - i0);
@@ -1072,6 +1101,7 @@ __global__ void __launch_bounds__(kTileW)
       if ((t & 63) == 0 && v != 0.0) atomicAdd(&monitor[k], v);
     }
   }
+  bool packed = false;  // this lane wrote a halo record
   if (FUSED) {
     int cnext = -1, wsn = -1;
     const double xp = xn, yp = yn;  // as integrated: what a halo message carries (the receiver runs its own K1)
@@ -1084,8 +1114,8 @@ __global__ void __launch_bounds__(kTileW)
     // slabs: the coming tick's halo message is packed here too (same rule and same pre-wall-fix position as
     // k_halo_pack); a workgroup-uniform branch, every lane of the wave takes part
     if (wn.slab && haloL)
-      halo_pack_one(active, xp, yp, vxn, vyn, idn, wn.d, wn.slab_axis, w.own_lo, w.own_hi, w.halo, w.has_left, w.has_right, haloL,
-                    haloR, haloCap, counters, part == 2);
+      packed = halo_pack_one(active, xp, yp, vxn, vyn, idn, wn.d, wn.slab_axis, w.own_lo, w.own_hi, w.halo, w.has_left,
+                             w.has_right, haloL, haloR, haloCap, counters, late_block);
   }
   SC_STAMP(1, 6);
   if (live) {
@@ -1096,6 +1126,36 @@ __global__ void __launch_bounds__(kTileW)
     ido[i] = idn;
   }
   SC_STAMP(1, 7);
+  if (BANDED && window_block) {  // part 3: this window block is done; the halo records it wrote become visible device-wide
+    const int wrote = __syncthreads_or(packed);
+    if (t == 0) {
+      // ONE release per block that wrote records, and only a release: a __threadfence() by every thread writes back
+      // AND invalidates the XCD's L2 three thousand times under the blocks that are still computing (measured: the
+      // kernel took twice as long)
+      if (wrote) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      const int nt = (n + kTileW - 1) / kTileW;
+      if (atomicAdd(&counters[C_BAND_DONE], 1) + 1 == min(2 * bandw, nt)) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // behind the other blocks' releases (one invalidate per launch)
+        counters[C_BAND_DONE] = 0;
+        __hip_atomic_store(&counters[C_BAND_FLAG], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+// The side stream's wait for the window blocks of a part-3 force kernel (hipStreamWaitValue32 is not usable on this
+// stack: scripts/wait_value_probe.hip).  One thread; gives up after ~50 ms and says so.
+__global__ void k_wait_band(int* __restrict__ counters, int epoch) {
+  const long long t0 = wall_clock64();
+  // (relaxed polls: an acquire per poll invalidates this XCD's caches under the force kernel that is running)
+  while (__hip_atomic_load(&counters[C_BAND_FLAG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch < 0) {
+    if (wall_clock64() - t0 > 5000000LL) {  // 100 MHz
+      atomicOr(&counters[C_FLAGS], F_BAND_TIMEOUT);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(64);
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
 }
 
 }  // namespace sc

@@ -219,6 +219,11 @@ class Engine:
     def set_slab(self, col_lo: int, col_hi: int, halo: int, has_left: bool, has_right: bool) -> None:
         N.check(self._lib.sc_set_slab(self._ctx, int(col_lo), int(col_hi), int(halo), int(has_left), int(has_right)))
 
+    def set_band_flag(self, on: bool) -> None:
+        """Halo overlap with slabs of rows: one launch of the force kernel + a polling kernel on the side stream
+        (sc_set_band_flag) instead of two launches."""
+        N.check(self._lib.sc_set_band_flag(self._ctx, int(bool(on))))
+
     def set_slab_axis(self, axis: int) -> None:
         """0: slabs are ranges of columns floor(x / d) (the default); 1: of rows floor(y / d)."""
         N.check(self._lib.sc_set_slab_axis(self._ctx, int(axis)))

@@ -185,6 +185,9 @@ class HipSlabBackend:
     def column_histogram(self, col0: int, n_columns: int) -> np.ndarray:
         return self.engine.column_histogram(col0, n_columns)
 
+    def set_band_flag(self, on: bool) -> None:
+        self.engine.set_band_flag(on)
+
     def set_overlap(self, on: bool) -> None:
         """Halo overlap: the exchange runs on the context's side stream next to the interior blocks of the force
         kernel (sc_set_halo_overlap)."""
@@ -233,7 +236,7 @@ class SlabCrate:
                  noise_seed: int = 0, group=None, backend=None, halo_capacity: int | None = None,
                  capacity: int | None = None, transport: str | None = None, rebalance_every: int = 0,
                  cuts: list[int] | None = None, overlap: bool | None = None, rank: int | None = None,
-                 world: int | None = None, axis: str = "x"):
+                 world: int | None = None, axis: str = "x", band_flag: bool = False):
         """`rank` / `world` given: a member of an in-process `SlabChain` (the chain moves the messages and adds the
         histograms); otherwise they come from torch.distributed."""
         import torch.distributed as dist
@@ -294,6 +297,7 @@ class SlabCrate:
         self.halo_capacity = int(halo_capacity)
         if overlap is None:  # by default only where a particle may cross many cells per tick and still be packed in time
             overlap = axis == "y"
+        self.band_flag = False
         self.overlap = bool(overlap) and self.world > 1 and hasattr(self.backend, "set_overlap")
         if self.overlap:
             self.backend.set_overlap(True)
@@ -313,6 +317,19 @@ class SlabCrate:
             # the torch.distributed fallback is the safety net: keep it on the context's own stream
             self.backend.set_overlap(False)
             self.overlap = False
+        if band_flag:
+            self.set_band_flag(True)
+
+    def set_band_flag(self, on: bool) -> bool:
+        """Halo overlap with slabs of rows in ONE launch of the force kernel plus a polling kernel on the side stream
+        (sc_set_band_flag) instead of two launches: cheaper when the side stream has a hardware queue of its own,
+        disastrous (a 50 ms time-out per tick, then an error) when it shares one with the context's stream.  Only
+        between exchanges (right after construction, `reload` or `synchronize` of a finished `run`).  -> in effect"""
+        on = bool(on) and self.overlap and self.axis == "y" and hasattr(self.backend, "set_band_flag")
+        if hasattr(self.backend, "set_band_flag"):
+            self.backend.set_band_flag(on)
+        self.band_flag = on
+        return on
 
     def reload(self, particles, velocities) -> None:
         """Start over from a state with the SAME particle positions as the one this object was built with (same
@@ -571,14 +588,14 @@ class SlabChain:
     def __init__(self, world_config, particles, velocities, n_slabs: int, *, device: int = 0, noise: str = "counter",
                  noise_seed: int = 0, halo_capacity: int | None = None, capacity: int | None = None,
                  rebalance_every: int = 0, cuts: list[int] | None = None, overlap: bool | None = None,
-                 backend_factory=None, axis: str = "x"):
+                 backend_factory=None, axis: str = "x", band_flag: bool = False):
         self.members = []
         for k in range(n_slabs):
             backend = backend_factory(k) if backend_factory is not None else None
             self.members.append(SlabCrate(copy.deepcopy(world_config), particles, velocities, device=device, noise=noise,
                                           noise_seed=noise_seed, halo_capacity=halo_capacity, capacity=capacity,
                                           rebalance_every=rebalance_every, cuts=cuts, overlap=overlap, rank=k,
-                                          world=n_slabs, backend=backend, axis=axis))
+                                          world=n_slabs, backend=backend, axis=axis, band_flag=band_flag))
         self.tick = 0
         self.message_records = []  # per tick: the records every message carried (left-to-right, then right-to-left)
 

@@ -12,15 +12,15 @@ n = per * nslab
 wc, d = bench.world_for(n)
 p, v = bench.synthetic_state(n)
 import itertools
-for overlap, cap in itertools.product((False, True), ("x", "y")):
-    chain = SlabChain(copy.deepcopy(wc), p, v, nslab, noise="counter", noise_seed=1, overlap=overlap, axis=cap)
+for overlap, cap, flag in ((False, "x", False), (False, "y", False), (True, "x", False), (True, "y", False), (True, "y", True)):
+    chain = SlabChain(copy.deepcopy(wc), p, v, nslab, noise="counter", noise_seed=1, overlap=overlap, axis=cap, band_flag=flag)
     chain.run(5); chain.synchronize()
     eng = chain.members[0].engine
     eng.reset_timing(); eng.enable_timing(True)
     t0 = time.perf_counter(); chain.run(20); chain.synchronize(); dt = (time.perf_counter() - t0) / 20
     eng.enable_timing(False)
     tm = {k: round(1000 * ms / 20, 1) for k, (ms, c) in eng.timing().items() if c}
-    print(f"chain of {nslab} x {per}, axis {cap}, overlap {overlap}: {dt*1e3:.4f} ms per tick for all slabs = {dt*1e3/nslab:.4f} per slab; member 0 kernels per tick: {tm}  sum {sum(tm.values()):.1f}", flush=True)
+    print(f"chain of {nslab} x {per}, axis {cap}, overlap {overlap}, one launch + flag {flag}: {dt*1e3:.4f} ms per tick for all slabs = {dt*1e3/nslab:.4f} per slab; member 0 kernels per tick: {tm}  sum {sum(tm.values()):.1f}", flush=True)
     del chain
 wc1, d1 = bench.world_for(per)
 p1, v1 = bench.synthetic_state(per)

@@ -271,17 +271,19 @@ def test_slabs_in_a_pile_up_state_equal_the_single_domain(sc, overlap):
     assert_chain_equals_single(chain, single)
 
 
-@pytest.mark.parametrize("overlap", [False, True])
-def test_row_slabs_equal_the_single_domain(sc, overlap):
-    """Slabs of rows (axis="y"): ghosts, migration, halo overlap and the look-ahead packing decided by floor(y / d);
-    the uniform workload with its motored wall, and the pile-up state."""
+@pytest.mark.parametrize("overlap,band_flag", [(False, False), (True, False), (True, True)])
+def test_row_slabs_equal_the_single_domain(sc, overlap, band_flag):
+    """Slabs of rows (axis="y"): ghosts, migration, halo overlap (as two launches of the force kernel, and as one whose
+    band blocks release the side stream through a polled flag) and the look-ahead packing decided by floor(y / d); the
+    uniform workload with its motored wall, and the pile-up state."""
     from sand_crate_amd.slab import SlabChain
     from test_gpu_parity import wave_world
     from test_gpu_round2 import pile_up_state
     n, ticks = 300000, 6
     wc, p, v, d = bench_world(n)
     single, _ = single_domain(sc, wc, p, v, ticks)
-    chain = SlabChain(copy.deepcopy(wc), p, v, 3, noise="counter", noise_seed=1, overlap=overlap, axis="y")
+    chain = SlabChain(copy.deepcopy(wc), p, v, 3, noise="counter", noise_seed=1, overlap=overlap, axis="y", band_flag=band_flag)
+    assert all(m.band_flag == band_flag for m in chain.members)  # (one launch of the force kernel + the polled flag)
     chain.run(ticks)
     chain.synchronize()
     assert min(chain.owned_counts()) > 0.8 * n / 3
