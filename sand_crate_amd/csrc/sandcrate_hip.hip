@@ -1405,8 +1405,7 @@ int sc_set_halo_overlap(sc_ctx* c, int on) {
 int sc_set_band_flag(sc_ctx* c, int on) {
   if (!c) return fail(SC_ERR_ARG, "null context");
   if (c->in_step) return fail(SC_ERR_STATE, "the band mode cannot change inside a tick");
-  if (c->band_pending) return fail(SC_ERR_STATE, "a halo message is under way");
-  c->band_by_flag = on != 0;
+  c->band_by_flag = on != 0;  // (a band that is pending keeps the announcement it was launched with: band_flagged)
   return SC_OK;
 }
 
