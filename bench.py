@@ -263,7 +263,7 @@ def main() -> None:
                     sim.run(8)
                     sim.synchronize()
                     seconds = time.perf_counter() - t0
-            except NativeError:
+            except (NativeError, RuntimeError):
                 pass
             t = torch.tensor([min(seconds, 1e9)], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else f"cuda:{local_rank}")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
