@@ -968,7 +968,8 @@ __global__ void __launch_bounds__(kTileW)
   // 1. one round trip: the three ranges (published by pass A for this very block), the particle's
   // scalars and all twenty table entries -- none of these loads waits for another
   const int ic = min(i, cap - 1);
-  const int* tb = tileBounds + 6 * tile_id;
+  // (a block between the windows may map beyond the last block of the arrays before the live count says so)
+  const int* tb = tileBounds + 6 * (BANDED ? min(tile_id, (cap - 1) / kTileW) : tile_id);
   const int tb0 = tb[0], tb1 = tb[1], tb2 = tb[2], tb3 = tb[3], tb4 = tb[4], tb5 = tb[5];
   const int cpacked = cell[ic];
   const int Craw = cnt[ic];
