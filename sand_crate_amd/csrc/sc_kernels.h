@@ -277,7 +277,8 @@ __global__ void __launch_bounds__(kBlock) k_scan_fix(int* __restrict__ out, int 
 // the block totals.  Readers add the two (struct Buckets).  Saves a ~5 us launch per tick.
 constexpr int kSortThreshold = 96;  // buckets above this many particles are listed for k_sort_big
 constexpr int kSortBlock = 256;
-constexpr int kSortChunk = 2048;       // slots per sorting task: 32 KB of LDS for (x, id, storage index)
+constexpr int kSortChunk = 2048;       // slots per sorting task (24 KB of LDS for the keys)
+constexpr int kSortBins = 256;         // bins of a chunk's x range
 constexpr int kRankMaxBuckets = 4096;  // big buckets sorted per tick = the room in the list (more: ranked in K4 by counting)
 constexpr int kBigTable = 3 * (kRankMaxBuckets + 1);  // k_sort_big's task table: start, length, tasks before, per bucket
 constexpr int kMaxBig = 4096;       // room in the list of big buckets
@@ -405,10 +406,14 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
 // compares; a pile of thousands of particles in one cell (stopped against a wall by the continuous-collision fix,
 // many with exactly equal x) made that the longest kernel of the tick -- in the contract workload's pile-up
 // regime half of all particles sit in such buckets.  Here every bucket the scan listed is cut into chunks of
-// kSortChunk slots and every chunk is sorted by (x, id) in LDS (bitonic network, one workgroup per chunk, the
-// storage index travels along) and written back in place: a bucket segment is in arrival order anyway, any
-// permutation of it is as good.  The bucket is stamped; K4 then takes a particle's rank as its position inside
-// its chunk plus, for buckets of several chunks, a binary search in each of the other chunks.
+// kSortChunk slots and every chunk is sorted by (x, id) by one workgroup -- a sample sort: 256 of its keys, sorted by a
+// bitonic network in LDS, split it into 256 bins (the keys are compared in their total order, so exact ties in x cannot
+// unbalance the bins), a key finds its bin by binary search and its rank inside the bin by counting over the ~8 keys
+// there -- and written back in place, the storage index travelling along: a bucket segment is in arrival order anyway,
+// any permutation of it is as good.  (A bitonic network over the whole chunk did the same in 84 us instead of 71 at
+// 1,048,576 particles; bins by x range instead of by samples took 196: the piles crowd against their wall.)  The bucket
+// is stamped; K4 then takes a particle's rank as its position inside its chunk plus, for buckets of several chunks, a
+// binary search in each of the other chunks.
 // Launched only when the previous tick saw big buckets; a bucket that is not stamped is ranked inside K4 by counting.
 // ------------------------------------------------------------------------------------------
 
@@ -419,9 +424,14 @@ __global__ void __launch_bounds__(kSortBlock)
                double* __restrict__ keyX, int* __restrict__ keyId, int* __restrict__ perm, int* __restrict__ sortedStamp,
                int stamp) {
   __shared__ int pre[kRankMaxBuckets + 1];  // tasks before bucket q (the scan built the table)
-  __shared__ double kx[kSortChunk];
-  __shared__ int kid[kSortChunk], kpm[kSortChunk];
-  const int tid = threadIdx.x;
+  __shared__ double ox[kSortChunk];         // the chunk's keys in bin order
+  __shared__ int oid[kSortChunk];
+  __shared__ int hist[kSortBins + 1];       // bin sizes, then bin starts
+  __shared__ double spx[kSortBins];  // the samples, sorted: splitters
+  __shared__ int spi[kSortBins];
+  __shared__ int waveTot[kSortBlock / 64];
+  static_assert(kSortBins == kSortBlock, "one thread per bin in the scan of the bin sizes");
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nbig = min(__hip_atomic_load(&counters[C_NBIG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), kRankMaxBuckets);
   if (nbig == 0) return;
   for (int q = tid; q <= nbig; q += kSortBlock) pre[q] = bigTable[2 * (kRankMaxBuckets + 1) + q];
@@ -435,41 +445,109 @@ __global__ void __launch_bounds__(kSortBlock)
     }
     const int q = lo, local = task - pre[q];
     const int b = bigTable[q] + local * kSortChunk, len = min(kSortChunk, bigTable[(kRankMaxBuckets + 1) + q] - local * kSortChunk);
-    int n = 64;  // the network's size: the power of two that holds the chunk
-    while (n < len) n <<= 1;
-    __syncthreads();  // the previous task's write-back has read the arrays
-    for (int e = tid; e < n; e += kSortBlock) {
-      const bool in = e < len;
-      kx[e] = in ? keyX[b + e] : __builtin_huge_val();  // padding sorts behind every key (ids are below INT_MAX)
-      kid[e] = in ? keyId[b + e] : 0x7FFFFFFF;
-      kpm[e] = in ? perm[b + e] : 0;
+    // 1. the chunk's keys, eight per thread
+    constexpr int kPerT = kSortChunk / kSortBlock;
+    double x[kPerT];
+    int id[kPerT], pm[kPerT], bin[kPerT], pos[kPerT];
+#pragma unroll
+    for (int u = 0; u < kPerT; ++u) {
+      const int e = tid + u * kSortBlock;
+      if (e < len) {
+        x[u] = keyX[b + e];
+        id[u] = keyId[b + e];
+        pm[u] = perm[b + e];
+      }
     }
+    // 2. splitters: every thread contributes one of its keys as a sample; the 256 samples are sorted (bitonic network in LDS, keys
+    // (x, id) in their total order -- exact ties in x cannot unbalance the bins) and the first 255 of them split the
+    // chunk into 256 bins of ~8 keys
+    __syncthreads();  // the previous task is done with the shared arrays
+    {
+      // thread t's sample is its (t mod 8)-th key when the chunk reaches that far: samples from all over the chunk (its
+      // arrival order follows the storage order, a sample of its head would know only one end of the x range)
+      double sx = tid < len ? x[0] : __builtin_huge_val();
+      int si = tid < len ? id[0] : 0x7FFFFFFF;
+#pragma unroll
+      for (int u = 1; u < kPerT; ++u) {
+        if ((tid & (kPerT - 1)) == u && tid + u * kSortBlock < len) {
+          sx = x[u];
+          si = id[u];
+        }
+      }
+      spx[tid] = sx;
+      spi[tid] = si;
+    }
+    hist[tid] = 0;
     __syncthreads();
-    for (int k = 2; k <= n; k <<= 1) {
+    for (int k = 2; k <= kSortBins; k <<= 1) {
       for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int e = tid; e < (n >> 1); e += kSortBlock) {
-          const int i = ((e & ~(j - 1)) << 1) | (e & (j - 1));  // e with a zero bit inserted at j's position
+        if (tid < kSortBins / 2) {
+          const int i = ((tid & ~(j - 1)) << 1) | (tid & (j - 1));
           const int p = i | j;
-          const double xa = kx[i], xb = kx[p];
-          const int ia = kid[i], ib = kid[p];
-          const bool up = (i & k) == 0;  // this pair sorts ascending
-          if (key_less(xb, ib, xa, ia) == up) {
-            kx[i] = xb;
-            kx[p] = xa;
-            kid[i] = ib;
-            kid[p] = ia;
-            const int pa = kpm[i];
-            kpm[i] = kpm[p];
-            kpm[p] = pa;
+          const double xa = spx[i], xb = spx[p];
+          const int ia = spi[i], ib = spi[p];
+          if (key_less(xb, ib, xa, ia) == ((i & k) == 0)) {
+            spx[i] = xb;
+            spx[p] = xa;
+            spi[i] = ib;
+            spi[p] = ia;
           }
         }
         __syncthreads();
       }
     }
-    for (int e = tid; e < len; e += kSortBlock) {
-      keyX[b + e] = kx[e];
-      keyId[b + e] = kid[e];
-      perm[b + e] = kpm[e];
+    // a key's bin: the splitters below it; its arrival number inside the bin
+#pragma unroll
+    for (int u = 0; u < kPerT; ++u) {
+      if (tid + u * kSortBlock < len) {
+        int lo2 = 0, hi2 = kSortBins - 1;  // splitters 0 .. 254
+        while (lo2 < hi2) {
+          const int mid = (lo2 + hi2) >> 1;
+          if (key_less(spx[mid], spi[mid], x[u], id[u])) lo2 = mid + 1; else hi2 = mid;
+        }
+        bin[u] = lo2;
+        pos[u] = atomicAdd(&hist[lo2], 1);
+      }
+    }
+    __syncthreads();
+    // 3. bin starts (exclusive scan of the sizes, one bin per thread)
+    {
+      const int v = hist[tid];
+      int incl = v;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t2 = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t2;
+      }
+      if (lane == 63) waveTot[wv] = incl;
+      __syncthreads();
+      int wbase = 0;
+      for (int k = 0; k < wv; ++k) wbase += waveTot[k];
+      hist[tid] = wbase + incl - v;
+      if (tid == kSortBlock - 1) hist[kSortBins] = wbase + incl;
+    }
+    __syncthreads();
+    // 4. keys to their bins
+#pragma unroll
+    for (int u = 0; u < kPerT; ++u) {
+      if (tid + u * kSortBlock < len) {
+        const int p = hist[bin[u]] + pos[u];
+        ox[p] = x[u];
+        oid[p] = id[u];
+      }
+    }
+    __syncthreads();
+    // 5. rank inside the bin by counting (a bin holds 8 keys on average; a bin of exact ties holds what it holds),
+    // and the record goes to its final slot of the chunk
+#pragma unroll
+    for (int u = 0; u < kPerT; ++u) {
+      if (tid + u * kSortBlock < len) {
+        const int s0 = hist[bin[u]], s1 = hist[bin[u] + 1];
+        int r = 0;
+        for (int m = s0; m < s1; ++m) r += key_less(ox[m], oid[m], x[u], id[u]);
+        keyX[b + s0 + r] = x[u];
+        keyId[b + s0 + r] = id[u];
+        perm[b + s0 + r] = pm[u];
+      }
     }
     if (local == 0 && tid == 0) sortedStamp[bigList[q]] = stamp;
   }
