@@ -1764,7 +1764,7 @@ int sc_emit_particles(sc_ctx* c, const sc_source* sources, int32_t n_sources, do
 }
 
 #ifdef SC_STAMPS
-// diagnostic build: copies the stamp buffer (2 kernels x 65536 waves x 16 slots, int64) to the host
+// diagnostic build: copies the stamp buffer (2 kernels x 65536 waves x kStampSlots slots, int64) to the host
 int sc_debug_stamps(sc_ctx* c, long long* out) {
   if (!c || !out) return fail(SC_ERR_ARG, "null argument");
   HIPCHK(hipStreamSynchronize(c->stream));

@@ -34,7 +34,7 @@ namespace sc {
 // stamp means "everything before is done".  The stamps go to a buffer no kernel reads (sc_debug_stamps reads it
 // on the host); the product build compiles none of this.
 #ifdef SC_STAMPS
-constexpr int kStampSlots = 16, kStampWaves = 1 << 16;
+constexpr int kStampSlots = 24, kStampWaves = 1 << 16;
 __device__ long long g_stamps[2][kStampWaves][kStampSlots];
 #define SC_STAMP(kernel, slot)                                                                          \
   do {                                                                                                   \
@@ -48,9 +48,17 @@ __device__ long long g_stamps[2][kStampWaves][kStampSlots];
     const int wv_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                                 \
     if ((threadIdx.x & 63) == 0 && wv_ < kStampWaves) g_stamps[kernel][wv_][slot] = (value);             \
   } while (0)
+#define SC_CLOCK(acc)                                                                                    \
+  do {                                                                                                   \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                         \
+    const long long now_ = __builtin_amdgcn_s_memtime();                                                 \
+    acc += now_ - dbg_last;                                                                              \
+    dbg_last = now_;                                                                                     \
+  } while (0)
 #else
 #define SC_STAMP(kernel, slot) do { } while (0)
 #define SC_STAMP_VALUE(kernel, slot, value) do { } while (0)
+#define SC_CLOCK(acc) do { } while (0)
 #endif
 
 // Tile geometry (measured, profiles/README.md): 256 particles per workgroup beat 128 by 2-3 % (less halo per
@@ -182,6 +190,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       constexpr int kHalf = CAP / 2, kSerial = 32;
 #ifdef SC_STAMPS
       long long dbg_rounds = 0, dbg_stagings = 0, dbg_wants = 0, dbg_coop = 0;
+      long long dbg_t_round = 0, dbg_t_stage = 0, dbg_t_serial = 0, dbg_t_coop = 0, dbg_t_other = 0, dbg_last = __builtin_amdgcn_s_memtime();
       int dbg_scan = 0;
 #endif
       const double dstop = w.d * (1.0 + 0x1p-20);
@@ -226,6 +235,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
 #ifdef SC_STAMPS
           dbg_wants |= (long long)__popcll(__ballot(left > 0)) << (8 * dbg_scan++);
 #endif
+          SC_CLOCK(dbg_t_other);
           for (;;) {
             // the unfinished position that is furthest behind, block-wide (keys double-buffered by round)
             int key = left > 0 ? pos * step : INT_MAX;
@@ -242,6 +252,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
             ++dbg_rounds;
 #endif
             const int p0 = k0 * step;
+            SC_CLOCK(dbg_t_round);
             if ((unsigned)(p0 - rws) >= (unsigned)CAP) {  // not in the resident window: stage the one around it
               rws = step > 0 ? (p0 / kHalf) * kHalf : max(0, (p0 / kHalf - 1) * kHalf);
 #ifdef SC_STAMPS
@@ -262,37 +273,35 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
                 if (rws + t + k * kTileW < total) txy[t + k * kTileW] = r[k];
               __syncthreads();
             }
+            SC_CLOCK(dbg_t_stage);
             const int ws = rws;
             auto inside = [&](int p) { return (unsigned)(p - ws) < (unsigned)CAP; };
             // kWinBatch candidates per iteration, their LDS reads issued together (a dependent read per candidate made
-            // this loop a chain of LDS latencies: in a pile 32 of them per thread and scan); examined one by one, in order
+            // this loop a chain of LDS latencies: in a pile 32 of them per thread and scan) and their verdicts formed
+            // side by side; what the scan does with them is then decided in order, as predicates instead of branches (a
+            // lone wave issues an instruction every 5-9 clocks: the branchy form spent a thousand clocks per batch)
             constexpr int kWinBatch = 4;
             for (int b = 0; b < kSerial && left > 0 && inside(pos); b += kWinBatch) {
+              const int avail = step > 0 ? ws + CAP - pos : pos - ws + 1;  // slots of the window from pos on
+              const int nv = min(min(left, avail), kWinBatch);             // candidates of this batch
               XY q[kWinBatch];
-              bool ok[kWinBatch];
+#pragma unroll
+              for (int k = 0; k < kWinBatch; ++k) q[k] = txy[k < nv ? pos + k * step - ws : 0];
+              bool over = false;
 #pragma unroll
               for (int k = 0; k < kWinBatch; ++k) {
-                const int pk = pos + k * step;
-                ok[k] = k < left && inside(pk);
-                q[k] = txy[ok[k] ? pk - ws : 0];
+                const int verdict = window(q[k].x, xi);
+                const double dx = q[k].x - xi, dy = q[k].y - yi;
+                const bool act = k < nv && !over;  // the scan gets as far as this candidate
+                const bool hit = act && verdict == 2 && dx * dx + dy * dy <= w.t_nbr;
+                if (hit) list[C][t] = (unsigned short)(pos + k * step);
+                C += hit ? 1 : 0;
+                over = over || (act && (verdict == 0 || C == kMaxNbr));
               }
-#pragma unroll
-              for (int k = 0; k < kWinBatch; ++k) {
-                if (ok[k] && left > 0) {  // left = 0: the scan ended at an earlier candidate of the batch
-                  const int verdict = window(q[k].x, xi);
-                  bool over = verdict == 0;
-                  if (verdict == 2) {
-                    const double dx = q[k].x - xi, dy = q[k].y - yi;
-                    if (dx * dx + dy * dy <= w.t_nbr) {
-                      list[C][t] = (unsigned short)pos;
-                      over = ++C == kMaxNbr;
-                    }
-                  }
-                  pos += step;
-                  left = over ? 0 : left - 1;
-                }
-              }
+              pos += nv * step;
+              left = over ? 0 : left - nv;
             }
+            SC_CLOCK(dbg_t_serial);
             unsigned long long m = __ballot(left > 0 && inside(pos));
             while (m) {
 #ifdef SC_STAMPS
@@ -359,7 +368,9 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
               }
               m = __ballot(left > 0 && inside(pos));
             }
+            SC_CLOCK(dbg_t_coop);
           }
+          SC_CLOCK(dbg_t_round);
         }
       };
       // same strip, after i: x_j <= x_i + d                                  (:106-109)
@@ -390,6 +401,11 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       SC_STAMP_VALUE(0, 13, dbg_stagings);
       SC_STAMP_VALUE(0, 14, dbg_wants);
       SC_STAMP_VALUE(0, 15, dbg_coop);
+      SC_STAMP_VALUE(0, 16, dbg_t_round);
+      SC_STAMP_VALUE(0, 17, dbg_t_stage);
+      SC_STAMP_VALUE(0, 18, dbg_t_serial);
+      SC_STAMP_VALUE(0, 19, dbg_t_coop);
+      SC_STAMP_VALUE(0, 20, dbg_t_other);
 #endif
     } else if (live) {
       // a tile beyond 65535 particles (a block inside one gigantic bucket) cannot use u16 slots:

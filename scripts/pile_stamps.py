@@ -13,7 +13,7 @@ p, v = bench.synthetic_state(n)
 s.particles = p; s.particle_velocities = v
 s.run(T); s.synchronize()
 lib = N.load()
-buf = np.zeros((2, 1 << 16, 16), dtype=np.int64)
+buf = np.zeros((2, 1 << 16, 24), dtype=np.int64)
 lib.sc_debug_stamps.restype = C.c_int
 lib.sc_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
 assert lib.sc_debug_stamps(s.engine._ctx, buf.ctypes.data_as(C.c_void_p)) == 0
@@ -34,6 +34,8 @@ for k, label in ((0, "pass A"), (1, "pass B")):
             if k == 0:
                 w = st[m][:, 14].astype(np.int64)
                 print(f"      rounds/wave {st[m][:,12].mean():.1f}  stagings {(st[m][:,13].astype(np.int64) & 255).mean():.1f}  coop steps {st[m][:,15].mean():.1f}  lanes wanting scan1..4: {(w & 255).mean():.1f} {((w>>8)&255).mean():.1f} {((w>>16)&255).mean():.1f} {((w>>24)&255).mean():.1f}")
+            if k == 0:
+                print("      ticks in the windowed scans: " + " ".join(f"{nm}={st[m][:, 16 + q].mean():.0f}" for q, nm in enumerate(["rounds+barriers", "staging", "serial", "wave-wide", "between scans"])))
             print(f"   tiles with {lo} <= entries < {hi}: {m.sum():6d} waves  total {life[m].sum():9.0f} us  mean {life[m].mean():7.1f} us  max {life[m].max():7.1f}   phases(ticks): " + " ".join(f"{nm}={x:.0f}" for nm, x in zip(names[k][1:], ph)))
     if k == 0:
         order = np.argsort(life)[-12:]
