@@ -1764,11 +1764,11 @@ int sc_emit_particles(sc_ctx* c, const sc_source* sources, int32_t n_sources, do
 }
 
 #ifdef SC_STAMPS
-// diagnostic build: copies the stamp buffer (2 kernels x 65536 waves x kStampSlots slots, int64) to the host
+// diagnostic build: copies the stamp buffer (kStampKernels x 65536 waves x kStampSlots slots, int64) to the host
 int sc_debug_stamps(sc_ctx* c, long long* out) {
   if (!c || !out) return fail(SC_ERR_ARG, "null argument");
   HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(sc::g_stamps), sizeof(long long) * 2 * sc::kStampWaves * sc::kStampSlots));
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(sc::g_stamps), sizeof(long long) * sc::kStampKernels * sc::kStampWaves * sc::kStampSlots));
   return SC_OK;
 }
 #endif

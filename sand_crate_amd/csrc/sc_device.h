@@ -178,4 +178,36 @@ __device__ __forceinline__ int wave_max(int v) {
   return v;
 }
 
+// Diagnostic build only (-DSC_STAMPS): per-wave clock stamps at phase boundaries, drained (s_waitcnt 0) so that a
+// stamp means "everything before is done".  The stamps go to a buffer no kernel reads (sc_debug_stamps reads it
+// on the host); the product build compiles none of this.
+#ifdef SC_STAMPS
+constexpr int kStampSlots = 24, kStampWaves = 1 << 16;
+constexpr int kStampKernels = 3;  // 0: pass A, 1: pass B, 2: k_sort_big
+__device__ long long g_stamps[kStampKernels][kStampWaves][kStampSlots];
+#define SC_STAMP(kernel, slot)                                                                          \
+  do {                                                                                                   \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                         \
+    const long long now_ = __builtin_amdgcn_s_memtime();                                                 \
+    const int wv_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                                 \
+    if ((threadIdx.x & 63) == 0 && wv_ < kStampWaves) g_stamps[kernel][wv_][slot] = now_;                \
+  } while (0)
+#define SC_STAMP_VALUE(kernel, slot, value)                                                             \
+  do {                                                                                                   \
+    const int wv_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                                 \
+    if ((threadIdx.x & 63) == 0 && wv_ < kStampWaves) g_stamps[kernel][wv_][slot] = (value);             \
+  } while (0)
+#define SC_CLOCK(acc)                                                                                    \
+  do {                                                                                                   \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                         \
+    const long long now_ = __builtin_amdgcn_s_memtime();                                                 \
+    acc += now_ - dbg_last;                                                                              \
+    dbg_last = now_;                                                                                     \
+  } while (0)
+#else
+#define SC_STAMP(kernel, slot) do { } while (0)
+#define SC_STAMP_VALUE(kernel, slot, value) do { } while (0)
+#define SC_CLOCK(acc) do { } while (0)
+#endif
+
 }  // namespace sc

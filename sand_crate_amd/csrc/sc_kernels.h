@@ -276,9 +276,15 @@ __global__ void __launch_bounds__(kBlock) k_scan_fix(int* __restrict__ out, int 
 // the cells is needed: every workgroup scans its block, and the last one to finish (ticket) scans
 // the block totals.  Readers add the two (struct Buckets).  Saves a ~5 us launch per tick.
 constexpr int kSortThreshold = 96;  // buckets above this many particles are listed for k_sort_big
-constexpr int kSortBlock = 256;
-constexpr int kSortChunk = 2048;       // slots per sorting task (24 KB of LDS for the keys)
-constexpr int kSortBins = 256;         // bins of a chunk's x range
+#ifndef SC_SORT_BLOCK
+#define SC_SORT_BLOCK 256
+#endif
+constexpr int kSortBlock = SC_SORT_BLOCK;  // threads of a sorting task
+#ifndef SC_SORT_CHUNK
+#define SC_SORT_CHUNK 1024
+#endif
+constexpr int kSortChunk = SC_SORT_CHUNK;  // slots per sorting task (12 B of LDS per slot for the keys)
+constexpr int kSortBins = 256;         // bins of a chunk (by sampled splitters)
 constexpr int kRankMaxBuckets = 4096;  // big buckets sorted per tick = the room in the list (more: ranked in K4 by counting)
 constexpr int kBigTable = 3 * (kRankMaxBuckets + 1);  // k_sort_big's task table: start, length, tasks before, per bucket
 constexpr int kMaxBig = 4096;       // room in the list of big buckets
@@ -407,11 +413,15 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
 // many with exactly equal x) made that the longest kernel of the tick -- in the contract workload's pile-up
 // regime half of all particles sit in such buckets.  Here every bucket the scan listed is cut into chunks of
 // kSortChunk slots and every chunk is sorted by (x, id) by one workgroup -- a sample sort: 256 of its keys, sorted by a
-// bitonic network in LDS, split it into 256 bins (the keys are compared in their total order, so exact ties in x cannot
-// unbalance the bins), a key finds its bin by binary search and its rank inside the bin by counting over the ~8 keys
-// there -- and written back in place, the storage index travelling along: a bucket segment is in arrival order anyway,
-// any permutation of it is as good.  (A bitonic network over the whole chunk did the same in 84 us instead of 71 at
-// 1,048,576 particles; bins by x range instead of by samples took 196: the piles crowd against their wall.)  The bucket
+// bitonic network (lane shuffles inside a wave, LDS across waves), split it into 256 bins (the keys are compared in their
+// total order, so exact ties in x cannot unbalance the bins), a key finds its bin by binary search and its rank inside the
+// bin by counting over the keys there -- and written back in place, the storage index travelling along: a bucket segment
+// is in arrival order anyway, any permutation of it is as good.  A task's time is a chain of latencies (less than one wave
+// per SIMD is resident) that grows with the keys per thread -- the bins' sizes are spread like an exponential, a wave
+// counts as long as its largest bin, about five times the mean, for every key of a thread -- so the chunk is 1024 slots,
+// not 2048: k_sort_big 56 -> 28 us at 1,048,576 particles in the pile-up regime, K4 32 -> 40 us for the extra searches.
+// (A bitonic network over a whole 2048-slot chunk took 84 us; bins by x range instead of by samples 196: the piles crowd
+// against their wall.)  The bucket
 // is stamped; K4 then takes a particle's rank as its position inside its chunk plus, for buckets of several chunks, a
 // binary search in each of the other chunks.
 // Launched only when the previous tick saw big buckets; a bucket that is not stamped is ranked inside K4 by counting.
@@ -429,8 +439,8 @@ __global__ void __launch_bounds__(kSortBlock)
   __shared__ int hist[kSortBins + 1];       // bin sizes, then bin starts
   __shared__ double spx[kSortBins];  // the samples, sorted: splitters
   __shared__ int spi[kSortBins];
-  __shared__ int waveTot[kSortBlock / 64];
-  static_assert(kSortBins == kSortBlock, "one thread per bin in the scan of the bin sizes");
+  __shared__ int waveTot[kSortBins / 64];
+  static_assert(kSortBins == 256 && kSortBlock >= kSortBins && kSortChunk % kSortBlock == 0, "the first 256 threads hold one sample / one bin each");
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nbig = min(__hip_atomic_load(&counters[C_NBIG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), kRankMaxBuckets);
   if (nbig == 0) return;
@@ -445,6 +455,8 @@ __global__ void __launch_bounds__(kSortBlock)
     }
     const int q = lo, local = task - pre[q];
     const int b = bigTable[q] + local * kSortChunk, len = min(kSortChunk, bigTable[(kRankMaxBuckets + 1) + q] - local * kSortChunk);
+    SC_STAMP_VALUE(2, 8, len);
+    SC_STAMP(2, 0);
     // 1. the chunk's keys, eight per thread
     constexpr int kPerT = kSortChunk / kSortBlock;
     double x[kPerT];
@@ -458,13 +470,15 @@ __global__ void __launch_bounds__(kSortBlock)
         pm[u] = perm[b + e];
       }
     }
-    // 2. splitters: every thread contributes one of its keys as a sample; the 256 samples are sorted (bitonic network in LDS, keys
+    SC_STAMP(2, 1);
+    // 2. splitters: every thread contributes one of its keys as a sample; the 256 samples are sorted (bitonic network, keys
     // (x, id) in their total order -- exact ties in x cannot unbalance the bins) and the first 255 of them split the
     // chunk into 256 bins of ~8 keys
     __syncthreads();  // the previous task is done with the shared arrays
     {
-      // thread t's sample is its (t mod 8)-th key when the chunk reaches that far: samples from all over the chunk (its
-      // arrival order follows the storage order, a sample of its head would know only one end of the x range)
+      // thread t < 256 contributes its (t mod kPerT)-th key as a sample when the chunk reaches that far: samples from all
+      // over the chunk (its arrival order follows the storage order, a sample of its head would know only one end of the
+      // x range)
       double sx = tid < len ? x[0] : __builtin_huge_val();
       int si = tid < len ? id[0] : 0x7FFFFFFF;
 #pragma unroll
@@ -474,58 +488,81 @@ __global__ void __launch_bounds__(kSortBlock)
           si = id[u];
         }
       }
-      spx[tid] = sx;
-      spi[tid] = si;
-    }
-    hist[tid] = 0;
-    __syncthreads();
-    for (int k = 2; k <= kSortBins; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        if (tid < kSortBins / 2) {
-          const int i = ((tid & ~(j - 1)) << 1) | (tid & (j - 1));
-          const int p = i | j;
-          const double xa = spx[i], xb = spx[p];
-          const int ia = spi[i], ib = spi[p];
-          if (key_less(xb, ib, xa, ia) == ((i & k) == 0)) {
-            spx[i] = xb;
-            spx[p] = xa;
-            spi[i] = ib;
-            spi[p] = ia;
+      // the network: a stage whose partners sit in the same wave exchanges through lane shuffles (33 of the 36 stages),
+      // only the three stages across waves go through LDS and a barrier (all 36 that way took 8 us of a 25 us task)
+#pragma unroll
+      for (int k = 2; k <= kSortBins; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          double px;
+          int pi;
+          if (j >= 64) {
+            __syncthreads();
+            if (tid < kSortBins) {
+              spx[tid] = sx;
+              spi[tid] = si;
+            }
+            __syncthreads();
+            px = spx[(tid ^ j) & (kSortBins - 1)];
+            pi = spi[(tid ^ j) & (kSortBins - 1)];
+          } else {
+            px = __shfl_xor(sx, j, 64);
+            pi = __shfl_xor(si, j, 64);
+          }
+          const bool keep_min = ((tid & j) == 0) == ((tid & k) == 0);
+          const bool partner_less = key_less(px, pi, sx, si);
+          if (keep_min ? partner_less : !partner_less) {
+            sx = px;
+            si = pi;
           }
         }
-        __syncthreads();
       }
-    }
-    // a key's bin: the splitters below it; its arrival number inside the bin
-#pragma unroll
-    for (int u = 0; u < kPerT; ++u) {
-      if (tid + u * kSortBlock < len) {
-        int lo2 = 0, hi2 = kSortBins - 1;  // splitters 0 .. 254
-        while (lo2 < hi2) {
-          const int mid = (lo2 + hi2) >> 1;
-          if (key_less(spx[mid], spi[mid], x[u], id[u])) lo2 = mid + 1; else hi2 = mid;
-        }
-        bin[u] = lo2;
-        pos[u] = atomicAdd(&hist[lo2], 1);
+      __syncthreads();
+      if (tid < kSortBins) {
+        spx[tid] = sx;
+        spi[tid] = si;
+        hist[tid] = 0;
       }
     }
     __syncthreads();
-    // 3. bin starts (exclusive scan of the sizes, one bin per thread)
+    SC_STAMP(2, 2);
+    // a key's bin: the splitters (0 .. 254) below it -- a lower bound in log2(bins) fixed steps, the searches of the
+    // thread's keys side by side (one after the other they were a chain of 8 x 8 dependent LDS round trips); then its
+    // arrival number inside the bin
+#pragma unroll
+    for (int u = 0; u < kPerT; ++u) bin[u] = 0;
+#pragma unroll
+    for (int h = kSortBins / 2; h >= 1; h >>= 1) {
+#pragma unroll
+      for (int u = 0; u < kPerT; ++u) {
+        const int m = bin[u] + h - 1;
+        if (key_less(spx[m], spi[m], x[u], id[u])) bin[u] += h;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kPerT; ++u)
+      if (tid + u * kSortBlock < len) pos[u] = atomicAdd(&hist[bin[u]], 1);
+    SC_STAMP(2, 3);
+    __syncthreads();
+    // 3. bin starts (exclusive scan of the sizes, one bin per thread of the first four waves)
     {
-      const int v = hist[tid];
+      const int v = tid < kSortBins ? hist[tid] : 0;
       int incl = v;
       for (int o = 1; o < 64; o <<= 1) {
         const int t2 = __shfl_up(incl, o, 64);
         if (lane >= o) incl += t2;
       }
-      if (lane == 63) waveTot[wv] = incl;
+      if (lane == 63 && tid < kSortBins) waveTot[wv] = incl;
       __syncthreads();
-      int wbase = 0;
-      for (int k = 0; k < wv; ++k) wbase += waveTot[k];
-      hist[tid] = wbase + incl - v;
-      if (tid == kSortBlock - 1) hist[kSortBins] = wbase + incl;
+      if (tid < kSortBins) {
+        int wbase = 0;
+        for (int k = 0; k < wv; ++k) wbase += waveTot[k];
+        hist[tid] = wbase + incl - v;
+        if (tid == kSortBins - 1) hist[kSortBins] = wbase + incl;
+      }
     }
     __syncthreads();
+    SC_STAMP(2, 4);
     // 4. keys to their bins
 #pragma unroll
     for (int u = 0; u < kPerT; ++u) {
@@ -536,6 +573,7 @@ __global__ void __launch_bounds__(kSortBlock)
       }
     }
     __syncthreads();
+    SC_STAMP(2, 5);
     // 5. rank inside the bin by counting (a bin holds 8 keys on average; a bin of exact ties holds what it holds),
     // and the record goes to its final slot of the chunk
 #pragma unroll
@@ -543,12 +581,34 @@ __global__ void __launch_bounds__(kSortBlock)
       if (tid + u * kSortBlock < len) {
         const int s0 = hist[bin[u]], s1 = hist[bin[u] + 1];
         int r = 0;
-        for (int m = s0; m < s1; ++m) r += key_less(ox[m], oid[m], x[u], id[u]);
+        for (int m = s0; m < s1; m += 4) {  // four entries per step, their LDS reads issued together
+          double qx[4];
+          int qi[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int mk = min(m + k, s1 - 1);
+            qx[k] = ox[mk];
+            qi[k] = oid[mk];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) r += (m + k < s1 && key_less(qx[k], qi[k], x[u], id[u])) ? 1 : 0;
+        }
         keyX[b + s0 + r] = x[u];
         keyId[b + s0 + r] = id[u];
         perm[b + s0 + r] = pm[u];
       }
     }
+#ifdef SC_STAMPS
+    {
+      int big = 0;
+#pragma unroll
+      for (int u = 0; u < kPerT; ++u)
+        if (tid + u * kSortBlock < len) big = max(big, hist[bin[u] + 1] - hist[bin[u]]);
+      for (int o = 32; o > 0; o >>= 1) big = max(big, __shfl_xor(big, o, 64));
+      SC_STAMP_VALUE(2, 9, big);
+    }
+#endif
+    SC_STAMP(2, 6);
     if (local == 0 && tid == 0) sortedStamp[bigList[q]] = stamp;
   }
 }

@@ -13,7 +13,7 @@ p, v = bench.synthetic_state(n)
 s.particles = p; s.particle_velocities = v
 s.run(T); s.synchronize()
 lib = N.load()
-buf = np.zeros((2, 1 << 16, 24), dtype=np.int64)
+buf = np.zeros((3, 1 << 16, 24), dtype=np.int64)
 lib.sc_debug_stamps.restype = C.c_int
 lib.sc_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
 assert lib.sc_debug_stamps(s.engine._ctx, buf.ctypes.data_as(C.c_void_p)) == 0
@@ -45,3 +45,16 @@ for k, label in ((0, "pass A"), (1, "pass B")):
         # how the kernel's critical path looks: start/end of waves relative to the first start (ticks -> us)
         t0 = st[:, 0].min()
         print(f"      kernel span by stamps {(st[:, 8].max() - t0) / 2100:.1f} us; waves starting after 100 us: {(st[:,0] - t0 > 100 * 2100).sum()}; last start {(st[:,0].max() - t0) / 2100:.1f} us")
+
+# k_sort_big: one task per workgroup (the first pass of its task loop), slots 0-6 = phase boundaries, slot 8 = keys in the task
+st = buf[2, :4 * 4096, :].astype(np.float64)
+st = st[st[:, 6] > 0]
+if len(st):
+    names2 = ["loaded", "samples sorted", "bins found", "bin starts", "keys binned", "ranked + stored"]
+    life = (st[:, 6] - st[:, 0]) / 2100.0
+    print(f"k_sort_big: {len(st)} waves, life median {np.median(life):.1f} us, max {life.max():.1f}; kernel span {(st[:, 6].max() - st[:, 0].min()) / 2100:.1f} us")
+    for lo, hi in ((0, 513), (513, 1025), (1025, 1537), (1537, 2049)):
+        m = (st[:, 8] >= lo) & (st[:, 8] < hi)
+        if m.any():
+            ph = np.diff(st[m][:, :7], axis=1).mean(axis=0)
+            print(f"   tasks of {lo}..{hi - 1} keys: {m.sum():5d} waves, life {life[m].mean():6.1f} us, phases (us): " + " ".join(f"{nm}={x / 2100:.1f}" for nm, x in zip(names2[0:], ph)) + f"; largest bin seen by a wave: mean {st[m][:, 9].mean():.0f}, max {st[m][:, 9].max():.0f}")
