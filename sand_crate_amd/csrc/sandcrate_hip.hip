@@ -92,7 +92,7 @@ struct sc_ctx {
   hipEvent_t ev_band = nullptr, ev_xchg = nullptr;
   int *cellCount = nullptr, *cellStart = nullptr, *blockSums = nullptr, *blockOff = nullptr, *sortedStamp = nullptr;
   int* bigList = nullptr;
-  int* bigTable = nullptr;  // k_sort_big's task table (start, length, tasks before, per listed bucket): the scan builds it
+  int* bigTable = nullptr;  // k_sort_big's task table (length, tasks before, per listed bucket): the scan builds it
   RcclComm comm = nullptr;  // RCCL communicator of the slab chain (sc_comm_init), or null
   int comm_rank = -1, comm_world = 0;
   double *haloL = nullptr, *haloR = nullptr;  // send buffers of the last sc_halo_pack (caller-owned device memory)
@@ -806,7 +806,7 @@ int sc_step_begin(sc_ctx* c) {
   if (piles_expected(c)) {
     Bracket br(c, K_SCAN);
     hipLaunchKernelGGL(k_sort_big, dim3(4 * c->num_cus), dim3(kSortBlock), 0, c->stream, c->counters, c->bigList,
-                       c->bigTable, c->keyX, c->keyId, c->perm, c->sortedStamp, stamp);
+                       c->bigTable, Buckets{c->cellStart, c->blockOff}, c->keyX, c->keyId, c->perm, c->sortedStamp, stamp);
   }
   {
     Bracket br(c, K_REORDER);

@@ -286,7 +286,7 @@ constexpr int kSortBlock = SC_SORT_BLOCK;  // threads of a sorting task
 constexpr int kSortChunk = SC_SORT_CHUNK;  // slots per sorting task (12 B of LDS per slot for the keys)
 constexpr int kSortBins = 256;         // bins of a chunk (by sampled splitters)
 constexpr int kRankMaxBuckets = 4096;  // big buckets sorted per tick = the room in the list (more: ranked in K4 by counting)
-constexpr int kBigTable = 3 * (kRankMaxBuckets + 1);  // k_sort_big's task table: start, length, tasks before, per bucket
+constexpr int kBigTable = 3 * (kRankMaxBuckets + 1);  // k_sort_big's task table: (unused), length, tasks before, per bucket
 constexpr int kMaxBig = 4096;       // room in the list of big buckets
 constexpr int kScanShift = 11;
 static_assert((1 << kScanShift) == kScanPerBlock, "block offset lookup assumes 2048 cells per scan block");
@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
       sum += e;
       if (e > kSortThreshold) {  // rare: a bucket worth sorting properly
         int q = atomicAdd(&counters[C_NBIG], 1);
-        if (q < kMaxBig) bigList[q] = base + k;
+        if (q < kMaxBig) __hip_atomic_store(&bigList[q], base + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     int incl = sum;
@@ -331,24 +331,36 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
 #pragma unroll
     for (int k = 0; k < kScanPerThread; ++k)
       if (base + k <= n) out[base + k] = excl + v[k];  // index n: one-past-the-end entry
-    if (threadIdx.x == kBlock - 1) blockSums[blockIdx.x] = excl + sum;
+    if (threadIdx.x == kBlock - 1)
+      __hip_atomic_store(&blockSums[blockIdx.x], excl + sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // ticket: the block totals of all workgroups are visible to the last one (agent-scope release by
-  // every publisher, acquire by the last; MI355X_MICROARCH.md, inter-workgroup visibility)
+  // ticket: what the last workgroup reads of the others -- the block totals and the list of big buckets, nothing
+  // else -- is stored at agent scope (past the XCD's L2) and has arrived before the ticket is drawn: every thread waits
+  // for its own stores, then the barrier, then the ticket.  A release fence here instead writes the XCD's whole L2
+  // back, once per workgroup, under a running kernel: 3 of 13 us at 1,048,576 particles, 16 of 35 at 4,194,304.
+  // The bucket starts (`out`) are plain stores: the kernels that follow read them, the last workgroup does not.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    last = atomicAdd(&counters[C_TICKET], 1) == (int)gridDim.x - 1;
-  }
+  if (threadIdx.x == 0)
+    last = __hip_atomic_fetch_add(&counters[C_TICKET], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
   __syncthreads();
   if (!last) return;
-  __threadfence();
+  __threadfence();  // acquire: nothing stale in this CU's caches
   const int nb = gridDim.x;
   int carry = 0;
-  for (int b0 = 0; b0 < nb; b0 += kBlock) {
-    int k = b0 + threadIdx.x;
-    int e = k < nb ? __hip_atomic_load(&blockSums[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    int incl = e;
+  // kSumsPerThread consecutive block totals per thread and pass, their loads issued together: 2048 totals (4 M cells)
+  // in one pass of load -> scan -> store instead of one pass per 256 -- this tail runs alone on the GPU
+  constexpr int kSumsPerThread = 8;
+  for (int b0 = 0; b0 < nb; b0 += kBlock * kSumsPerThread) {
+    const int k0 = b0 + threadIdx.x * kSumsPerThread;
+    int e[kSumsPerThread];
+#pragma unroll
+    for (int j = 0; j < kSumsPerThread; ++j)
+      e[j] = k0 + j < nb ? __hip_atomic_load(&blockSums[k0 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < kSumsPerThread; ++j) mine += e[j];
+    int incl = mine;
     for (int o = 1; o < 64; o <<= 1) {
       int t = __shfl_up(incl, o, 64);
       if (lane >= o) incl += t;
@@ -361,7 +373,12 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
       if (q < wv) wbase += waveTot[q];
       tot += waveTot[q];
     }
-    if (k < nb) blockOff[k] = carry + wbase + incl - e;
+    int excl = carry + wbase + incl - mine;
+#pragma unroll
+    for (int j = 0; j < kSumsPerThread; ++j) {
+      if (k0 + j < nb) blockOff[k0 + j] = excl;
+      excl += e[j];
+    }
     carry += tot;
   }
   const int nbig_all = __hip_atomic_load(&counters[C_NBIG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -372,7 +389,7 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
     // synchronisation when the NEXT tick is enqueued and only decides whether k_sort_big is launched.
     bigHint[0] = nbig_all;
   }
-  // k_sort_big's task table, built once here: per listed bucket its start, its length and the sorting tasks before it
+  // k_sort_big's task table, built once here: per listed bucket its length and the sorting tasks before it
   const int nbig = min(nbig_all, kRankMaxBuckets);
   if (nbig == 0) return;  // uniform
   __syncthreads();        // blockOff is complete
@@ -382,11 +399,10 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
     int t = 0;
     if (q < nbig) {
       const int c = __hip_atomic_load(&bigList[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int b = __hip_atomic_load(&out[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + blockOff[c >> kScanShift];
-      const int e = __hip_atomic_load(&out[c + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + blockOff[(c + 1) >> kScanShift];
-      bigTable[q] = b;
-      bigTable[(kRankMaxBuckets + 1) + q] = e - b;
-      t = (e - b + kSortChunk - 1) / kSortChunk;
+      const int len = in[c];  // the bucket's size is its cell's count (the previous kernel's work); its start is the
+                              // other workgroups' `out`, which k_sort_big looks up itself
+      bigTable[(kRankMaxBuckets + 1) + q] = len;
+      t = (len + kSortChunk - 1) / kSortChunk;
     }
     int incl = t;
     for (int o = 1; o < 64; o <<= 1) {
@@ -431,7 +447,7 @@ __device__ __forceinline__ bool key_less(double xa, int ia, double xb, int ib) {
 
 __global__ void __launch_bounds__(kSortBlock)
     k_sort_big(const int* __restrict__ counters, const int* __restrict__ bigList, const int* __restrict__ bigTable,
-               double* __restrict__ keyX, int* __restrict__ keyId, int* __restrict__ perm, int* __restrict__ sortedStamp,
+               Buckets bk, double* __restrict__ keyX, int* __restrict__ keyId, int* __restrict__ perm, int* __restrict__ sortedStamp,
                int stamp) {
   __shared__ int pre[kRankMaxBuckets + 1];  // tasks before bucket q (the scan built the table)
   __shared__ double ox[kSortChunk];         // the chunk's keys in bin order
@@ -454,7 +470,7 @@ __global__ void __launch_bounds__(kSortBlock)
       if (pre[mid] <= task) lo = mid; else hi = mid;
     }
     const int q = lo, local = task - pre[q];
-    const int b = bigTable[q] + local * kSortChunk, len = min(kSortChunk, bigTable[(kRankMaxBuckets + 1) + q] - local * kSortChunk);
+    const int b = bk(bigList[q]) + local * kSortChunk, len = min(kSortChunk, bigTable[(kRankMaxBuckets + 1) + q] - local * kSortChunk);
     SC_STAMP_VALUE(2, 8, len);
     SC_STAMP(2, 0);
     // 1. the chunk's keys, eight per thread
