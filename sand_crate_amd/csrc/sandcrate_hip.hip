@@ -81,6 +81,7 @@ struct sc_ctx {
   int *cellS = nullptr, *wslotS = nullptr, *cellT = nullptr, *wslotT = nullptr, *perm = nullptr;
   double* keyX = nullptr;
   int* keyId = nullptr;
+  int* keyCell = nullptr;  // the packed cell of the particle in a bucket slot (k_scatter writes it next to the key)
   int* tileBounds = nullptr;   // per block of kTileW sorted particles: its three candidate ranges (k_reorder)
   int* tileBoundsT = nullptr;  // ... the three ranges its neighbor-table slots refer to (the search; sc_tiled.h)
   int* tileBand = nullptr;  // per block of pass A / B: holds a particle that may be packed into a halo message
@@ -591,6 +592,7 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
   if (e == hipSuccess) e = dalloc(&c->perm, n);
   if (e == hipSuccess) e = dalloc(&c->keyX, n);
   if (e == hipSuccess) e = dalloc(&c->keyId, n);
+  if (e == hipSuccess) e = dalloc(&c->keyCell, n);
   if (e == hipSuccess) e = dalloc(&c->tileBounds, 6 * (n / kTileW + 2));
   if (e == hipSuccess) e = dalloc(&c->tileBoundsT, 6 * (n / kTileW + 2));
   if (e == hipSuccess) e = dalloc(&c->tileBand, n / kTileW + 2);
@@ -635,7 +637,7 @@ int sc_destroy(sc_ctx* c) {
   }
   if (c->ev_band) (void)hipEventDestroy(c->ev_band);
   if (c->ev_xchg) (void)hipEventDestroy(c->ev_xchg);
-  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->tileBounds, c->tileBoundsT, c->tileBand, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->bigTable, c->wrec[0], c->wrec[1],
+  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->keyCell, c->tileBounds, c->tileBoundsT, c->tileBand, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->bigTable, c->wrec[0], c->wrec[1],
                   c->nbr, c->nbr16, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
                   c->stage_xy, c->stage_vxy, c->stage_ids, c->owned_out, c->colHist, c->rng, c->monitor,
                   c->snap_d[0], c->snap_d[1], c->snap_d[2], c->snap_d[3], c->snap_id_d, c->snap_rng_d};
@@ -795,10 +797,10 @@ int sc_step_begin(sc_ctx* c) {
     Bracket br(c, K_SCATTER);
     if (piles_expected(c))
       hipLaunchKernelGGL(k_scatter<true>, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->cellS, c->x[0],
-                         c->id[0], Buckets{c->cellStart, c->blockOff}, c->cellCount, c->perm, c->keyX, c->keyId, cap, w.live_hint);
+                         c->id[0], Buckets{c->cellStart, c->blockOff}, c->cellCount, c->perm, c->keyX, c->keyId, c->keyCell, cap, w.live_hint);
     else
       hipLaunchKernelGGL(k_scatter<false>, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->cellS, c->x[0],
-                         c->id[0], Buckets{c->cellStart, c->blockOff}, c->cellCount, c->perm, c->keyX, c->keyId, cap, w.live_hint);
+                         c->id[0], Buckets{c->cellStart, c->blockOff}, c->cellCount, c->perm, c->keyX, c->keyId, c->keyCell, cap, w.live_hint);
   }
   const int stamp = (int)((c->tick + 1) & 0x3FFFFFFF);
   // big buckets were seen by the last scan the host knows about (an unsynchronised, possibly stale
@@ -811,7 +813,7 @@ int sc_step_begin(sc_ctx* c) {
   {
     Bracket br(c, K_REORDER);
     hipLaunchKernelGGL(k_reorder, dim3((int)std::max<int64_t>(1, (launch_bound(c) + kReorderBlock - 1) / kReorderBlock)),
-                       dim3(kReorderBlock), 0, c->stream, c->counters, c->perm, c->keyX, c->keyId,
+                       dim3(kReorderBlock), 0, c->stream, c->counters, c->perm, c->keyX, c->keyId, c->keyCell,
                        c->cellS, Buckets{c->cellStart, c->blockOff}, c->wslotS, c->y[0], c->vx[0], c->vy[0], c->x[1], c->y[1], c->vx[1],
                        c->vy[1], c->id[1], c->cellT, c->wslotT, c->sortedStamp, stamp, w.ncols, c->tileBounds, w.live_hint);
   }

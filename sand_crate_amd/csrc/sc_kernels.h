@@ -656,10 +656,12 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ coun
                                                     const double* __restrict__ xS, const int* __restrict__ idS,
                                                     Buckets bk, int* __restrict__ cellCount,
                                                     int* __restrict__ perm, double* __restrict__ keyX,
-                                                    int* __restrict__ keyId, int cap, int live_hint) {
+                                                    int* __restrict__ keyId, int* __restrict__ keyCell, int cap,
+                                                    int live_hint) {
   int i = chunk_of_block(live_hint) * blockDim.x + threadIdx.x;
   const int ic = min(i, cap - 1);  // loads that do not depend on the stored count go out first
   int c = cellS[ic];
+  const int cpacked = c;
   const double xi = xS[ic];
   const int idi = idS[ic];
   if (i >= counters[C_NS]) c = -1;
@@ -705,6 +707,7 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ coun
   perm[pos] = i;
   keyX[pos] = xi;
   keyId[pos] = idi;
+  keyCell[pos] = cpacked;  // K4 finds the ends of a small bucket from its neighbors' cells instead of looking them up
 }
 
 // ------------------------------------------------------------------------------------------
@@ -719,9 +722,11 @@ constexpr int kRankChunk = 256;   // keys streamed through LDS per step (3 KB pe
                                   // of gathers and needs the waves; with 1024 the LDS held it to 13 waves per CU, 27.6 -> 23.7 us)
 constexpr int kReorderBlock = 64; // one wave per workgroup: a big bucket is shared by 4x more CUs
 
+constexpr int kRankWindow = 12;   // slots either side of a particle in which a small bucket's ends are looked for
+
 __global__ void __launch_bounds__(kReorderBlock)
     k_reorder(const int* __restrict__ counters, const int* __restrict__ perm, const double* __restrict__ keyX,
-              const int* __restrict__ keyId, const int* __restrict__ cellS, Buckets bk,
+              const int* __restrict__ keyId, const int* __restrict__ keyCell, const int* __restrict__ cellS, Buckets bk,
               const int* __restrict__ wslotS, const double* __restrict__ yS, const double* __restrict__ vxS,
               const double* __restrict__ vyS, double* __restrict__ xT, double* __restrict__ yT,
               double* __restrict__ vxT, double* __restrict__ vyT, int* __restrict__ idT, int* __restrict__ cellT,
@@ -729,30 +734,70 @@ __global__ void __launch_bounds__(kReorderBlock)
               int* __restrict__ tileBounds, int live_hint) {
   __shared__ double ckx[kRankChunk];
   __shared__ int cki[kRankChunk];
+  __shared__ int wcell[kReorderBlock + 2 * kRankWindow];
   __shared__ int pick;
+  static_assert(kReorderBlock + 2 * kRankWindow <= kRankChunk && 2 * kRankWindow - 1 <= kBigBucket, "window fits, and what it resolves is a small bucket");
   const int s = chunk_of_block(live_hint) * blockDim.x + threadIdx.x;
   const int nlive = counters[C_NT];
   if (s - (int)threadIdx.x >= nlive) return;  // a block beyond the live particles (a slab's grid covers its capacity)
   const bool live = s < nlive;
   int i = 0, idi = 0, cpacked = 0, c = 0, wsi = 0, b = 0, e = 0;
   double xi = 0, yi = 0, vxi = 0, vyi = 0;
+  // The kernel is a chain of dependent round trips at full occupancy, so its time is the chain's length.  The bucket of
+  // a particle used to cost three of them (storage index -> cell -> bucket starts -> the bucket's keys); now the scatter
+  // leaves the cell next to the key and the workgroup reads the keys and cells of its 64 slots and kRankWindow slots
+  // either side in one coalesced sweep: a bucket whose two ends show inside the window (nearly all: a cell holds 4
+  // particles on average) is ranked from LDS while the gathers by storage index are still in flight.
+  if (live) i = perm[s];
+  {
+    const int s0 = s - (int)threadIdx.x;
+    for (int w = threadIdx.x; w < kReorderBlock + 2 * kRankWindow; w += kReorderBlock) {
+      const int slot = s0 - kRankWindow + w;
+      const bool ok = slot >= 0 && slot < nlive;
+      const int sl = ok ? slot : s0;
+      const int cw = keyCell[sl];
+      ckx[w] = keyX[sl];
+      cki[w] = keyId[sl];
+      wcell[w] = ok ? cw : -1;  // packed (ghost bit and all); -1: no slot
+    }
+  }
   if (live) {
-    i = perm[s];
-    xi = keyX[s];
-    idi = keyId[s];
-    cpacked = cellS[i];
-    c = cpacked & kCellMask;
     yi = yS[i];
     vxi = vxS[i];
     vyi = vyS[i];
     wsi = wslotS[i];
-    b = bk(c);
-    e = bk(c + 1);
   }
+  __syncthreads();
   int rank = 0;
+  bool resolved = false;
+  if (live) {
+    const int w0 = threadIdx.x + kRankWindow;
+    cpacked = wcell[w0];
+    c = cpacked & kCellMask;
+    xi = ckx[w0];
+    idi = cki[w0];
+    auto same = [&](int v) { return v >= 0 && (v & kCellMask) == c; };
+    int nl = 0, nr = 0;  // slots of the same cell to the left / right
+    while (nl < kRankWindow && same(wcell[w0 - nl - 1])) ++nl;
+    while (nr < kRankWindow && same(wcell[w0 + nr + 1])) ++nr;
+    resolved = nl < kRankWindow && nr < kRankWindow;
+    if (resolved) {
+      b = s - nl;
+      e = s + nr + 1;
+      for (int w = w0 - nl; w <= w0 + nr; ++w) {
+        const double kx = ckx[w];
+        rank += (kx < xi) || (kx == xi && cki[w] < idi);
+      }
+    } else {
+      cpacked = cellS[i];  // k_sort_big moves keys and storage indices inside a bucket, not the cells next to them
+      b = bk(c);
+      e = bk(c + 1);
+    }
+  }
+  __syncthreads();  // the window is read; ckx / cki serve the big buckets below
   // a bucket k_sort_big has sorted this tick, chunk by chunk: the rank is the position inside the particle's chunk
   // plus the keys below (x, id) in each of the bucket's other chunks
-  const bool presorted = live && (e - b) > kSortThreshold && sortedStamp[c] == stamp;
+  const bool presorted = live && !resolved && (e - b) > kSortThreshold && sortedStamp[c] == stamp;
   if (presorted) {
     const int mine = (s - b) / kSortChunk;
     rank = (s - b) - mine * kSortChunk;
@@ -767,8 +812,8 @@ __global__ void __launch_bounds__(kReorderBlock)
       rank += lo - cb;
     }
   }
-  const bool big = live && !presorted && (e - b) > kBigBucket;
-  if (live && !big && !presorted) {
+  const bool big = live && !resolved && !presorted && (e - b) > kBigBucket;
+  if (live && !resolved && !big && !presorted) {
     for (int t = b; t < e; t += 4) {  // four keys in flight per round trip
       double k0 = keyX[t], k1 = t + 1 < e ? keyX[t + 1] : xi, k2 = t + 2 < e ? keyX[t + 2] : xi,
              k3 = t + 3 < e ? keyX[t + 3] : xi;
