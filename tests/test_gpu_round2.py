@@ -409,3 +409,31 @@ def test_tiles_just_over_the_force_kernels_budget_match_the_oracle(sc):
         np.testing.assert_allclose(gv, out["velocities"], rtol=1e-9, atol=1e-10)
         np.testing.assert_allclose(gpr, out["pressure"], rtol=1e-9, atol=1e-12)
         p, v = gp, gv
+
+
+def test_bucket_sizes_around_every_ranking_path(sc):
+    """k_reorder ranks a bucket from a window of 12 slots either side when both of its ends show there, from the
+    bucket's keys in global memory up to 24, cooperatively above, and from k_sort_big's chunks (1024 slots) above 96:
+    buckets of every size around those edges, side by side in one row (so that the windows hold other buckets' keys),
+    with exact ties in x, at the very start and the very end of the sorted order -> the reference's (row, x, id)
+    order (oracle/neighbors.py: strip_sort, pinned by the golden cases)."""
+    from oracle.neighbors import strip_sort
+    rs = np.random.RandomState(17)
+    d = 0.05
+    sizes = [1, 2, 11, 12, 13, 14, 22, 23, 24, 25, 26, 40, 95, 96, 97, 98, 130, 1023, 1024, 1025, 2047, 2048, 2049, 3, 12, 13, 1]
+    pts = []
+    for row, shuffle in ((0, False), (3, True)):  # row 3: the same sizes in another order, ties everywhere
+        order = rs.permutation(len(sizes)) if shuffle else np.arange(len(sizes))
+        for k, j in enumerate(order):
+            n = sizes[j]
+            x = (k + rs.rand(n) * 0.999) * d
+            if shuffle or n % 2 == 0:  # exact ties: a handful of distinct x per cell
+                x = (k + np.round(rs.rand(n) * 5) / 5.01 * 0.999) * d
+            pts.append(np.column_stack((x, (row + rs.rand(n) * 0.999) * d)))
+    pts = np.vstack(pts)
+    pts = pts[rs.permutation(len(pts))]
+    rows, order, counts, table = sc.neighbor_search(pts, d)
+    ref_rows, ref_order = strip_sort(pts, d)
+    assert np.array_equal(order, ref_order)
+    assert np.array_equal(rows, ref_rows)
+    assert counts.max() <= 20 and len(table) == len(pts)  # the lists themselves: test_pile_up_buckets_sort_and_rank
