@@ -464,11 +464,19 @@ int64_t launch_bound(const sc_ctx* c) { return c->slab ? c->cap : c->upper; }
 int tile_grid(const sc_ctx* c) { return (int)std::max<int64_t>(1, (launch_bound(c) + kTileW - 1) / kTileW); }
 
 // neighbor search (+ pass A unless the host's noise block has to be indexed first)
+bool piles_expected(const sc_ctx* c);
+
 template <int NOISE, bool ENUM, bool DENS, int CAP>
 void launch_pass_a_cap(sc_ctx* c) {
-  hipLaunchKernelGGL((k_pass_a<NOISE, ENUM, DENS, CAP>), dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters,
-                     c->x[1], c->y[1], c->id[1], c->cellT, Buckets{c->cellStart, c->blockOff}, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta, c->offById,
-                     c->P, c->sx, c->sy, ENUM ? c->tileBounds : c->tileBoundsT, c->tileBand, c->tileBoundsT);
+  auto launch = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters,
+                       c->x[1], c->y[1], c->id[1], c->cellT, Buckets{c->cellStart, c->blockOff}, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta, c->offById,
+                       c->P, c->sx, c->sy, ENUM ? c->tileBounds : c->tileBoundsT, c->tileBand, c->tileBoundsT);
+  };
+  if (ENUM && DENS && piles_expected(c))  // dense tiles ahead: the instantiation that stages their lists' reach
+    launch(k_pass_a<NOISE, ENUM, DENS, CAP, ENUM && DENS>);
+  else
+    launch(k_pass_a<NOISE, ENUM, DENS, CAP, false>);
 }
 
 template <int NOISE, bool ENUM, bool DENS>

@@ -109,7 +109,7 @@ __device__ __forceinline__ int tile_of_block_ends_first(int tiles) {
 }
 
 // Phases 3-5 of pass A for one particle.  LDS: where the tile is (compile time, see the header).
-template <int NOISE, bool ENUM, bool DENS, bool LDS, int CAP>
+template <int NOISE, bool ENUM, bool DENS, bool LDS, int CAP, bool STAGE = false>
 __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, const int total, XY* txy,
                                             unsigned short (*list)[kTileW + 2], int* wkey, const int t, const int i,
                                             const bool live, const int idi, const int e0, const int b0, const int b1,
@@ -422,6 +422,99 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
   C = 0;
 #endif
   SC_STAMP(0, 6);
+  // 3b. The table's slots refer to the ranges published in tileBoundsT -- for the usual tile the candidate ranges.  A
+  // tile whose candidate ranges exceed pass B's LDS budget (a block in or beside a pile: thousands of candidates,
+  // of which the lists name a few hundred) publishes the ranges its lists actually reach instead -- per range from
+  // the lowest to the highest slot named, the block's own particles included -- and renumbers its entries, so that
+  // pass B stages these tiles in LDS like any other instead of gathering every neighbor from global memory.  A tile
+  // that was searched through the window does the same for its own pair math: the reach (a few hundred entries) is
+  // staged in the window's LDS and the entries are renumbered in the lists before the pair loop, which then reads its
+  // neighbors like an LDS tile's (gathered from global memory, four per round trip, it took three times as long).
+  const int sr1 = tl.n0, sr2 = tl.n0 + tl.n1;  // first slot of the next rows' / previous rows' range
+  const bool strim = STAGE && ENUM && slots_fit && total > kTileCapB;  // uniform over the workgroup
+  bool staged = false;                       // the reach is in txy and the lists hold renumbered entries
+  // The reach, from the waves' extremes in wkey: nb[0..5] = the three index ranges, sub[0..2] = what renumbering takes
+  // off an entry of each range; -> entries in all.  Derived where it is needed (here for the staging, below for the
+  // table) rather than kept: a dozen uniform values alive across the pair loop spilled scalar registers in every tile.
+  auto reach = [&](int* nb, int* sub) -> int {
+    int lo0 = INT_MAX, hi0 = -1, lo1 = INT_MAX, hi1 = -1, lo2 = INT_MAX, hi2 = -1;
+#pragma unroll
+    for (int k = 0; k < kTileW / 64; ++k) {
+      const int* wk = wkey + 6 * k;
+      lo0 = min(lo0, wk[0]); hi0 = max(hi0, wk[1]);
+      lo1 = min(lo1, wk[2]); hi1 = max(hi1, wk[3]);
+      lo2 = min(lo2, wk[4]); hi2 = max(hi2, wk[5]);
+    }
+    const int m0 = hi0 - lo0 + 1;  // never empty: the block's own particles
+    const int m1 = hi1 >= lo1 ? hi1 - lo1 + 1 : 0, m2 = hi2 >= lo2 ? hi2 - lo2 + 1 : 0;
+    if (m1 == 0) lo1 = sr1;
+    if (m2 == 0) lo2 = sr2;
+    nb[0] = tl.a0 + lo0;
+    nb[1] = nb[0] + m0;
+    nb[2] = tl.a1 + (lo1 - sr1);
+    nb[3] = nb[2] + m1;
+    nb[4] = tl.a2 + (lo2 - sr2);
+    nb[5] = nb[4] + m2;
+    sub[0] = lo0;
+    sub[1] = lo1 - m0;
+    sub[2] = lo2 - m0 - m1;
+    return m0 + m1 + m2;
+  };
+  // the waves' extremes of the slots the lists name, per range, into wkey (every thread of the workgroup calls this)
+  auto extremes = [&]() {
+    int lo0 = live ? self : INT_MAX, hi0 = live ? self : -1, lo1 = INT_MAX, hi1 = -1, lo2 = INT_MAX, hi2 = -1;
+    if (live)
+      for (int s = 0; s < C; ++s) {
+        const int e = list[s][t];
+        if (e < sr1) {
+          lo0 = min(lo0, e);
+          hi0 = max(hi0, e);
+        } else if (e < sr2) {
+          lo1 = min(lo1, e);
+          hi1 = max(hi1, e);
+        } else {
+          lo2 = min(lo2, e);
+          hi2 = max(hi2, e);
+        }
+      }
+    for (int o = 32; o > 0; o >>= 1) {
+      lo0 = min(lo0, __shfl_xor(lo0, o, 64));
+      hi0 = max(hi0, __shfl_xor(hi0, o, 64));
+      lo1 = min(lo1, __shfl_xor(lo1, o, 64));
+      hi1 = max(hi1, __shfl_xor(hi1, o, 64));
+      lo2 = min(lo2, __shfl_xor(lo2, o, 64));
+      hi2 = max(hi2, __shfl_xor(hi2, o, 64));
+    }
+    __syncthreads();  // the scans are done with wkey (and with the window)
+    if ((t & 63) == 0) {
+      int* wk = wkey + 6 * (t >> 6);
+      wk[0] = lo0; wk[1] = hi0; wk[2] = lo1; wk[3] = hi1; wk[4] = lo2; wk[5] = hi2;
+    }
+    __syncthreads();
+  };
+  if constexpr (STAGE && !LDS) if (strim) {
+    extremes();
+    if constexpr (!LDS) {
+      if (DENS) {
+        int nb[6], sub[3];
+        const int mt = reach(nb, sub);
+        if (mt <= CAP) {  // uniform
+          staged = true;
+          if (live)
+            for (int s = 0; s < C; ++s) {
+              const int e = list[s][t];
+              list[s][t] = (unsigned short)(e - (e < sr1 ? sub[0] : e < sr2 ? sub[1] : sub[2]));
+            }
+          const Tile part{nb[0], nb[1] - nb[0], nb[2], nb[3] - nb[2], nb[4], nb[5] - nb[4]};
+          for (int slot = t; slot < mt; slot += kTileW) {
+            const int j = tile_index(part, slot);
+            txy[slot] = XY{x[j], y[j]};
+          }
+          __syncthreads();
+        }
+      }
+    }
+  }
   // 4. pair math of pass A: populate_colliders (crate.py:161-175), pressures (:261-275), normals (:337-342)
   if (DENS && live) {
     // no decision is taken in this block (P, s are float-tolerance outputs): multiply-adds may fuse here although the
@@ -444,6 +537,21 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
 #else
     const int Cloop = C;
 #endif
+    if (STAGE && !LDS && staged) {  // the neighbors are in the staged reach: an LDS tile's loop
+      for (int s = 0; s < Cloop; ++s) {
+        const XY q = txy[list[s][t]];
+        double rx, ry;
+        pair_offset<NOISE>(w, z, s, eta, off, pi.x - q.x, pi.y - q.y, rx, ry);
+        z += kGold;
+        const double s2 = rx * rx + ry * ry;
+        const double rinv = rsqrt_nr(s2);
+        const double c = fmin(fmax(s2 * rinv * w.inv_d, 0.0), 1.0);
+        sumc += c;
+        const double g = c * (1 - c) * rinv;
+        ax += g * rx;
+        ay += g * ry;
+      }
+    } else
     for (int s = 0; s < Cloop; ++s) {
       if (s % kFetch == 0) {
 #pragma unroll
@@ -484,6 +592,27 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
   // of which the lists name a few hundred) publishes the ranges its lists actually reach instead -- per range from
   // the lowest to the highest slot named, the block's own particles included -- and renumbers its entries, so that
   // pass B stages these tiles in LDS like any other instead of gathering every neighbor from global memory.
+  if constexpr (STAGE && !LDS) {
+    int nb[6] = {tl.a0, tl.a0 + tl.n0, tl.a1, tl.a1 + tl.n1, tl.a2, tl.a2 + tl.n2}, sub[3] = {0, 0, 0};
+    if (strim) reach(nb, sub);
+    if (t == 0) {
+      int* tbT = tileBoundsT + 6 * tile_id;
+      tbT[0] = nb[0]; tbT[1] = nb[1]; tbT[2] = nb[2]; tbT[3] = nb[3]; tbT[4] = nb[4]; tbT[5] = nb[5];
+    }
+    if (live) {
+      if (slots_fit) {
+        if (strim && !staged) {
+          for (int s = 0; s < C; ++s) {
+            const int e = list[s][t];
+            nbr16[(size_t)s * cap + i] = (unsigned short)(e - (e < sr1 ? sub[0] : e < sr2 ? sub[1] : sub[2]));
+          }
+        } else {
+          for (int s = 0; s < C; ++s) nbr16[(size_t)s * cap + i] = list[s][t];
+        }
+      }
+      cnt[i] = (unsigned char)C;
+    }
+  } else
   if (ENUM) {
     int nb0 = tl.a0, nb1 = tl.a0 + tl.n0, nb2 = tl.a1, nb3 = tl.a1 + tl.n1, nb4 = tl.a2, nb5 = tl.a2 + tl.n2;
     const int r1 = tl.n0, r2 = tl.n0 + tl.n1;  // first slot of the next rows' / previous rows' range
@@ -573,7 +702,10 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
 // indexed after all counts are known: then <ENUM only> runs in sc_step_begin and <DENS only> in
 // sc_step_finish.
 // ------------------------------------------------------------------------------------------
-template <int NOISE, bool ENUM, bool DENS, int CAP>
+// STAGE: tiles searched through the window stage the reach of their lists for the pair math (pass_a_body, 3b).  Its own
+// instantiation, launched while the scans report big buckets: inlined into the one kernel the extra paths cost the
+// uniform regime 13 spilled scalar registers and 1 us per tick.
+template <int NOISE, bool ENUM, bool DENS, int CAP, bool STAGE = false>
 __global__ void __launch_bounds__(kTileW)
     k_pass_a(World w, const int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
              const int* __restrict__ id, const int* __restrict__ cell, Buckets bk,
@@ -689,7 +821,7 @@ __global__ void __launch_bounds__(kTileW)
       bm = bk(c - w.ncols - 1);
       em = bk(c - w.ncols + 2);
     }
-    pass_a_body<NOISE, ENUM, DENS, false, CAP>(w, tl, total, txy, list, wkey, t, ip, livep, idp, e0, b0, b1, e1, bm, em, x, y, nbr,
+    pass_a_body<NOISE, ENUM, DENS, false, CAP, STAGE && ENUM && DENS>(w, tl, total, txy, list, wkey, t, ip, livep, idp, e0, b0, b1, e1, bm, em, x, y, nbr,
                                           nbr16, cnt, cap, eta, offById, P, sx, sy, tile_id, tileBoundsT);
   }
 }
