@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <climits>
 
 #include "sandcrate_hip.h"
 
@@ -167,6 +168,28 @@ __device__ __forceinline__ LaneRun lane_run(int key) {
   r.len = next - head;
   r.is_head = is_head;
   return r;
+}
+
+// Wave-wide minimum / maximum, the same value in every lane: four row shifts and two row broadcasts on the DPP path
+// (12 vector instructions and a v_readlane) instead of six rounds through the LDS crossbar (ds_bpermute: ~100 clocks
+// each for a wave on its own).  Every lane of the wave must call these.
+__device__ __forceinline__ int wave_min_all(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x118, 0xf, 0xf, false));  // row_shr:8: lane 15 of a row holds the row
+  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1 and 3
+  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max_all(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x111, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x112, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x114, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x118, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x142, 0xa, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x143, 0xc, 0xf, false));
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 __device__ __forceinline__ int wave_sum(int v) {

@@ -207,8 +207,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
           SC_CLOCK(dbg_t_other);
           for (;;) {
             // the unfinished position that is furthest behind, block-wide (keys double-buffered by round)
-            int key = left > 0 ? pos * step : INT_MAX;
-            for (int o = 32; o > 0; o >>= 1) key = min(key, __shfl_down(key, o, 64));
+            const int key = wave_min_all(left > 0 ? pos * step : INT_MAX);
             int* wk = wkey + (round & 1) * (kTileW / 64);
             ++round;
             if (lane == 0) wk[t >> 6] = key;
@@ -477,14 +476,12 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
           hi2 = max(hi2, e);
         }
       }
-    for (int o = 32; o > 0; o >>= 1) {
-      lo0 = min(lo0, __shfl_xor(lo0, o, 64));
-      hi0 = max(hi0, __shfl_xor(hi0, o, 64));
-      lo1 = min(lo1, __shfl_xor(lo1, o, 64));
-      hi1 = max(hi1, __shfl_xor(hi1, o, 64));
-      lo2 = min(lo2, __shfl_xor(lo2, o, 64));
-      hi2 = max(hi2, __shfl_xor(hi2, o, 64));
-    }
+    lo0 = wave_min_all(lo0);
+    hi0 = wave_max_all(hi0);
+    lo1 = wave_min_all(lo1);
+    hi1 = wave_max_all(hi1);
+    lo2 = wave_min_all(lo2);
+    hi2 = wave_max_all(hi2);
     __syncthreads();  // the scans are done with wkey (and with the window)
     if ((t & 63) == 0) {
       int* wk = wkey + 6 * (t >> 6);
@@ -634,14 +631,12 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
             hi2 = max(hi2, e);
           }
         }
-      for (int o = 32; o > 0; o >>= 1) {
-        lo0 = min(lo0, __shfl_xor(lo0, o, 64));
-        hi0 = max(hi0, __shfl_xor(hi0, o, 64));
-        lo1 = min(lo1, __shfl_xor(lo1, o, 64));
-        hi1 = max(hi1, __shfl_xor(hi1, o, 64));
-        lo2 = min(lo2, __shfl_xor(lo2, o, 64));
-        hi2 = max(hi2, __shfl_xor(hi2, o, 64));
-      }
+      lo0 = wave_min_all(lo0);
+      hi0 = wave_max_all(hi0);
+      lo1 = wave_min_all(lo1);
+      hi1 = wave_max_all(hi1);
+      lo2 = wave_min_all(lo2);
+      hi2 = wave_max_all(hi2);
       __syncthreads();  // the scans are done with wkey
       if ((t & 63) == 0) {
         int* wk = wkey + 6 * (t >> 6);
