@@ -192,6 +192,28 @@ __device__ __forceinline__ int wave_max_all(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
+// Lane i's copy of lane (i ^ J)'s value: on the DPP path for J below 16 (quad permutes, row shifts under bank masks,
+// a row rotate), through the LDS crossbar otherwise.  Every lane of the wave must call this.
+template <int J>
+__device__ __forceinline__ int xor_lane(int v) {
+  if constexpr (J == 1) {
+    return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);  // quad_perm:[1,0,3,2]
+  } else if constexpr (J == 2) {
+    return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);  // quad_perm:[2,3,0,1]
+  } else if constexpr (J == 4) {
+    const int r = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false);  // row_shl:4 into lanes 0-3, 8-11 of a row
+    return __builtin_amdgcn_update_dpp(r, v, 0x114, 0xf, 0xa, false);        // row_shr:4 into lanes 4-7, 12-15
+  } else if constexpr (J == 8) {
+    return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);  // row_ror:8
+  } else {
+    return __shfl_xor(v, J, 64);
+  }
+}
+template <int J>
+__device__ __forceinline__ double xor_lane(double v) {
+  return __hiloint2double(xor_lane<J>(__double2hiint(v)), xor_lane<J>(__double2loint(v)));
+}
+
 __device__ __forceinline__ int wave_sum(int v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   return v;

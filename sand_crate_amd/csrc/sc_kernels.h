@@ -435,7 +435,8 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
 // is in arrival order anyway, any permutation of it is as good.  A task's time is a chain of latencies (less than one wave
 // per SIMD is resident) that grows with the keys per thread -- the bins' sizes are spread like an exponential, a wave
 // counts as long as its largest bin, about five times the mean, for every key of a thread -- so the chunk is 1024 slots,
-// not 2048: k_sort_big 56 -> 28 us at 1,048,576 particles in the pile-up regime, K4 32 -> 40 us for the extra searches.
+// not 2048: k_sort_big 56 -> 28 us at 1,048,576 particles in the pile-up regime (26 with the network on the DPP path),
+// K4 32 -> 40 us for the extra searches.
 // (A bitonic network over a whole 2048-slot chunk took 84 us; bins by x range instead of by samples 196: the piles crowd
 // against their wall.)  The bucket
 // is stamped; K4 then takes a particle's rank as its position inside its chunk plus, for buckets of several chunks, a
@@ -504,34 +505,43 @@ __global__ void __launch_bounds__(kSortBlock)
           si = id[u];
         }
       }
-      // the network: a stage whose partners sit in the same wave exchanges through lane shuffles (33 of the 36 stages),
-      // only the three stages across waves go through LDS and a barrier (all 36 that way took 8 us of a 25 us task)
+      // the network: a stage whose partners sit in the same wave exchanges lane to lane -- on the DPP path when they are
+      // less than 16 lanes apart (26 of the 36 stages), through the LDS crossbar for 16 and 32 (7) --, only the three
+      // stages across waves go through LDS and a barrier (all 36 that way took 8 us of a 25 us task)
+      auto stage = [&](int k, int j, double px, int pi) {
+        const bool keep_min = ((tid & j) == 0) == ((tid & k) == 0);
+        const bool partner_less = key_less(px, pi, sx, si);
+        if (keep_min ? partner_less : !partner_less) {
+          sx = px;
+          si = pi;
+        }
+      };
 #pragma unroll
       for (int k = 2; k <= kSortBins; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-          double px;
-          int pi;
-          if (j >= 64) {
-            __syncthreads();
-            if (tid < kSortBins) {
-              spx[tid] = sx;
-              spi[tid] = si;
-            }
-            __syncthreads();
-            px = spx[(tid ^ j) & (kSortBins - 1)];
-            pi = spi[(tid ^ j) & (kSortBins - 1)];
-          } else {
-            px = __shfl_xor(sx, j, 64);
-            pi = __shfl_xor(si, j, 64);
+        if (k >= 256) {
+          __syncthreads();
+          if (tid < kSortBins) {
+            spx[tid] = sx;
+            spi[tid] = si;
           }
-          const bool keep_min = ((tid & j) == 0) == ((tid & k) == 0);
-          const bool partner_less = key_less(px, pi, sx, si);
-          if (keep_min ? partner_less : !partner_less) {
-            sx = px;
-            si = pi;
-          }
+          __syncthreads();
+          stage(k, 128, spx[(tid ^ 128) & (kSortBins - 1)], spi[(tid ^ 128) & (kSortBins - 1)]);
         }
+        if (k >= 128) {
+          __syncthreads();
+          if (tid < kSortBins) {
+            spx[tid] = sx;
+            spi[tid] = si;
+          }
+          __syncthreads();
+          stage(k, 64, spx[(tid ^ 64) & (kSortBins - 1)], spi[(tid ^ 64) & (kSortBins - 1)]);
+        }
+        if (k >= 64) stage(k, 32, xor_lane<32>(sx), xor_lane<32>(si));
+        if (k >= 32) stage(k, 16, xor_lane<16>(sx), xor_lane<16>(si));
+        if (k >= 16) stage(k, 8, xor_lane<8>(sx), xor_lane<8>(si));
+        if (k >= 8) stage(k, 4, xor_lane<4>(sx), xor_lane<4>(si));
+        if (k >= 4) stage(k, 2, xor_lane<2>(sx), xor_lane<2>(si));
+        stage(k, 1, xor_lane<1>(sx), xor_lane<1>(si));
       }
       __syncthreads();
       if (tid < kSortBins) {

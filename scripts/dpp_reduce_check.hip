@@ -1,4 +1,4 @@
-// Wave-wide min / max through DPP row shifts and broadcasts (gfx9 family) against the shuffle tree, on random data.
+// Wave-wide min / max and the xor-lane exchanges on the DPP path (gfx9 family) against the shuffles, on random data.
 //   hipcc -O3 --offload-arch=gfx950 -Isand_crate_amd/csrc -Iinclude scripts/dpp_reduce_check.hip -o /tmp/dpp_check && /tmp/dpp_check
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -13,7 +13,12 @@ __global__ void k(const int* in, int* out) {
     mx = max(mx, __shfl_xor(mx, o, 64));
   }
   const int a = sc::wave_min_all(v), b = sc::wave_max_all(v);
-  out[blockIdx.x * blockDim.x + threadIdx.x] = (a == mn && b == mx) ? 0 : 1;
+  bool ok = a == mn && b == mx;
+  ok = ok && sc::xor_lane<1>(v) == __shfl_xor(v, 1, 64) && sc::xor_lane<2>(v) == __shfl_xor(v, 2, 64) && sc::xor_lane<4>(v) == __shfl_xor(v, 4, 64) &&
+       sc::xor_lane<8>(v) == __shfl_xor(v, 8, 64) && sc::xor_lane<16>(v) == __shfl_xor(v, 16, 64) && sc::xor_lane<32>(v) == __shfl_xor(v, 32, 64);
+  const double dv = (double)v * 1.0000001;
+  ok = ok && sc::xor_lane<4>(dv) == __shfl_xor(dv, 4, 64) && sc::xor_lane<8>(dv) == __shfl_xor(dv, 8, 64);
+  out[blockIdx.x * blockDim.x + threadIdx.x] = ok ? 0 : 1;
 }
 int main() {
   const int n = 1 << 20;
