@@ -192,6 +192,17 @@ __device__ __forceinline__ int wave_max_all(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
+// Inclusive prefix sum over the lanes of a wave (lane i: v_0 + ... + v_i), on the DPP path like the reductions above.
+__device__ __forceinline__ int wave_scan_add(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8: prefix sums inside every row of 16
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15: rows 1, 3 += the row before
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31: rows 2, 3 += rows 0 + 1
+  return v;
+}
+
 // Lane i's copy of lane (i ^ J)'s value: on the DPP path for J below 16 (quad permutes, row shifts under bank masks,
 // a row rotate), through the LDS crossbar otherwise.  Every lane of the wave must call this.
 template <int J>

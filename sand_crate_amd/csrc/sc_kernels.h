@@ -234,11 +234,7 @@ __global__ void __launch_bounds__(kBlock) k_scan_local(const int* __restrict__ i
     sum += e;
   }
   int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int incl = sum;
-  for (int o = 1; o < 64; o <<= 1) {
-    int t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
-  }
+  const int incl = wave_scan_add(sum);
   if (lane == 63) waveTot[wv] = incl;
   __syncthreads();
   int wbase = 0;
@@ -318,11 +314,7 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
         if (q < kMaxBig) __hip_atomic_store(&bigList[q], base + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    int incl = sum;
-    for (int o = 1; o < 64; o <<= 1) {
-      int t = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += t;
-    }
+    const int incl = wave_scan_add(sum);
     if (lane == 63) waveTot[wv] = incl;
     __syncthreads();
     int wbase = 0;
@@ -360,11 +352,7 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
     int mine = 0;
 #pragma unroll
     for (int j = 0; j < kSumsPerThread; ++j) mine += e[j];
-    int incl = mine;
-    for (int o = 1; o < 64; o <<= 1) {
-      int t = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += t;
-    }
+    const int incl = wave_scan_add(mine);
     __syncthreads();
     if (lane == 63) waveTot[wv] = incl;
     __syncthreads();
@@ -404,11 +392,7 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
       bigTable[(kRankMaxBuckets + 1) + q] = len;
       t = (len + kSortChunk - 1) / kSortChunk;
     }
-    int incl = t;
-    for (int o = 1; o < 64; o <<= 1) {
-      const int u = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += u;
-    }
+    const int incl = wave_scan_add(t);
     __syncthreads();
     if (lane == 63) waveTot[wv] = incl;
     __syncthreads();
@@ -573,11 +557,7 @@ __global__ void __launch_bounds__(kSortBlock)
     // 3. bin starts (exclusive scan of the sizes, one bin per thread of the first four waves)
     {
       const int v = tid < kSortBins ? hist[tid] : 0;
-      int incl = v;
-      for (int o = 1; o < 64; o <<= 1) {
-        const int t2 = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t2;
-      }
+      const int incl = wave_scan_add(v);
       if (lane == 63 && tid < kSortBins) waveTot[wv] = incl;
       __syncthreads();
       if (tid < kSortBins) {

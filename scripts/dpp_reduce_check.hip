@@ -16,6 +16,15 @@ __global__ void k(const int* in, int* out) {
   bool ok = a == mn && b == mx;
   ok = ok && sc::xor_lane<1>(v) == __shfl_xor(v, 1, 64) && sc::xor_lane<2>(v) == __shfl_xor(v, 2, 64) && sc::xor_lane<4>(v) == __shfl_xor(v, 4, 64) &&
        sc::xor_lane<8>(v) == __shfl_xor(v, 8, 64) && sc::xor_lane<16>(v) == __shfl_xor(v, 16, 64) && sc::xor_lane<32>(v) == __shfl_xor(v, 32, 64);
+  {
+    const int small = v & 1023;
+    int incl = small;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if ((int)(threadIdx.x & 63) >= o) incl += u;
+    }
+    ok = ok && sc::wave_scan_add(small) == incl;
+  }
   const double dv = (double)v * 1.0000001;
   ok = ok && sc::xor_lane<4>(dv) == __shfl_xor(dv, 4, 64) && sc::xor_lane<8>(dv) == __shfl_xor(dv, 8, 64);
   out[blockIdx.x * blockDim.x + threadIdx.x] = ok ? 0 : 1;
