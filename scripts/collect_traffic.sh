@@ -13,6 +13,6 @@ mkdir -p $OUT
 hipcc -O3 --offload-arch=gfx950 scripts/traffic_calib.hip -o /tmp/traffic_calib
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/calib_$c -- /tmp/traffic_calib > $OUT/calib_$c.log 2>&1
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/bench_$c -- python bench.py --particles $N --cpu-sample 0 --no-kernel-events --repeats 1 --steps 20 --warmup 5 > $OUT/bench_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/bench_$c -- python bench.py --particles $N --cpu-sample 0 --no-kernel-events --repeats 1 --clock-warmup 0 --steps 20 --warmup 5 > $OUT/bench_$c.log 2>&1
 done
 python scripts/summarize_traffic.py $OUT $N

@@ -9,7 +9,7 @@ N=${2:-1048576}
 mkdir -p gpurun_out
 python bench.py --particles $N > gpurun_out/${TAG}_bench_$N.json 2> gpurun_out/${TAG}_bench_$N.err || tail -5 gpurun_out/${TAG}_bench_$N.err
 rm -rf gpurun_out/${TAG}_stats_$N
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats_$N -- python bench.py --particles $N --cpu-sample 0 --no-kernel-events --repeats 1 > gpurun_out/${TAG}_stats_$N.log 2>&1 || tail -5 gpurun_out/${TAG}_stats_$N.log
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats_$N -- python bench.py --particles $N --cpu-sample 0 --no-kernel-events --repeats 1 --clock-warmup 0 > gpurun_out/${TAG}_stats_$N.log 2>&1 || tail -5 gpurun_out/${TAG}_stats_$N.log
 cp gpurun_out/${TAG}_stats_$N/*/*kernel_stats.csv gpurun_out/${TAG}_kernel_stats_$N.csv 2>/dev/null
 scripts/collect_traffic.sh $N > gpurun_out/${TAG}_traffic_$N.log 2>&1 || tail -5 gpurun_out/${TAG}_traffic_$N.log
 cp profiles/r02_traffic_$N.json gpurun_out/ 2>/dev/null
