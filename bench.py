@@ -10,7 +10,9 @@ particle has ~12 neighbors, dt scaled with d, collider_noise_level 0.1 from a co
 N=4 / N=8: configs[3] / configs[4] (4,194,304 / 16,777,216 particles in all, slabs of rows, halo exchange per tick);
 N=2: 1,048,576 per GPU.  A step is one `physics_tick` of all particles; state is resident in HBM before the
 timed region and nothing is read back inside it.  The W+K-step measurement is repeated (--repeats, default 5)
-from the same initial state; `value` is the median repetition, all repetitions are listed.
+from the same initial state; `value` is the median repetition, all repetitions are listed.  On one GPU a second
+context of the same size runs --clock-warmup ticks (default 100) right before every repetition's W warm-up steps: the
+timed region is a few milliseconds behind an upload and would otherwise find the GPU's clocks down.
 
 Prints ONE JSON line (rank 0).  Besides the contract keys it carries
   roofline      SURVEY.md M4's force-pair figure: 128 algorithmic bytes per particle / (pass A + pass B) measured
