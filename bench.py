@@ -10,8 +10,8 @@ particle has ~12 neighbors, dt scaled with d, collider_noise_level 0.1 from a co
 N=4 / N=8: configs[3] / configs[4] (4,194,304 / 16,777,216 particles in all, slabs of rows, halo exchange per tick);
 N=2: 1,048,576 per GPU.  A step is one `physics_tick` of all particles; state is resident in HBM before the
 timed region and nothing is read back inside it.  The W+K-step measurement is repeated (--repeats, default 5)
-from the same initial state; `value` is the median repetition, all repetitions are listed.  On one GPU a second
-context of the same size runs --clock-warmup ticks (default 100) right before every repetition's W warm-up steps: the
+from the same initial state; `value` is the median repetition, all repetitions are listed.  A second
+context of the same size (N > 1: a single-domain one of a slab's size, on every rank) runs --clock-warmup ticks (default 100) right before every repetition's W warm-up steps: the
 timed region is a few milliseconds behind an upload and would otherwise find the GPU's clocks down.
 
 Prints ONE JSON line (rank 0).  Besides the contract keys it carries
@@ -222,7 +222,7 @@ def main() -> None:
                          "at 1, 2 and 4 GPUs, 2,097,152 per GPU -- 16,777,216 in all -- at 8)")
     ap.add_argument("--clock-warmup", type=int, default=100,
                     help="ticks a second context of the same size runs before each repetition's warm-up steps (GPU clocks; "
-                         "single GPU only; 0: off)")
+                         "N > 1: a single-domain context of a slab's size on every rank; 0: off)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the W+K-step measurement is repeated this many times from the same initial state; `value` is the "
                          "median repetition (each repetition times exactly K steps)")
@@ -370,8 +370,13 @@ def main() -> None:
     # timed steps find the clocks where a longer run has them (repetitions used to get faster from the first to the
     # last by 2-3 %).  Its work is over before the timed region starts (device-wide synchronize below).
     heater = None
-    if world == 1 and args.clock_warmup > 0:
-        heater = make_sim()
+    if args.clock_warmup > 0:
+        if world == 1:
+            heater = make_sim()
+        else:  # every rank heats its own GPU with a single-domain workload of a slab's size: no communication
+            hw, _ = world_for(per_gpu)
+            heater = sc.Crate(hw, device=local_rank, noise=args.noise, noise_seed=1, capacity=per_gpu + 1024)
+            heater.particles, heater.particle_velocities = synthetic_state(per_gpu)
     reps = []
     sim = None
     for _ in range(max(1, args.repeats)):
@@ -424,7 +429,7 @@ def main() -> None:
             "repeats": {"count": len(reps), "ms_per_step": [round(1000.0 * r / args.steps, 5) for r in reps],
                         "min": round(1000.0 * order[0] / args.steps, 5), "max": round(1000.0 * order[-1] / args.steps, 5),
                         "value_is": "median repetition",
-                        "clock_warmup_ticks_before_each": args.clock_warmup if world == 1 else 0},
+                        "clock_warmup_ticks_before_each": args.clock_warmup},
             "config": {"workload": f"{per_gpu} synthetic uniform particles per GPU ({n_total} total), "
                                    f"wave_machine.yaml world incl. the motored wall, d=sqrt(12/(pi*P)) (~12 neighbors), "
                                    f"collider noise 0.1 ({args.noise} RNG), ticks {args.warmup}..{args.warmup + args.steps - 1}",
