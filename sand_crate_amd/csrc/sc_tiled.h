@@ -163,8 +163,12 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       int dbg_scan = 0;
 #endif
       const double dstop = w.d * (1.0 + 0x1p-20);
-      unsigned short* lp = &list[0][t];                  // next free entry of this thread's list (LDS tiles)
-      unsigned short* const lend = &list[kMaxNbr][t];
+      // next free entry of this thread's list (LDS tiles) as a byte offset into `list`; row kMaxNbr is a spare one that
+      // takes the writes of a full list, so that an append is a store and a clamped add -- no branch
+      constexpr unsigned kRow = (kTileW + 2) * sizeof(unsigned short);
+      char* const lbase = (char*)&list[0][0];
+      const unsigned lo0 = t * (unsigned)sizeof(unsigned short), lend = kMaxNbr * kRow + lo0;
+      unsigned lo = lo0;
       auto scan = [&](bool want, int first, int count, int step, auto window) {
         if constexpr (LDS) {
           // kBatch candidates per iteration: their LDS reads are issued together (one latency per batch
@@ -176,27 +180,26 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
           // The last candidate of a batch may lie one to kBatch - 1 slots past the range: the tile array has that
           // much padding at both ends, what is read there is never a hit (v + k < count).  x is monotone along a
           // scan, so the last candidate of the batch decides the stop.
-          bool done = !want || lp == lend;
+          bool done = !want || lo == lend;
           for (int v = 0; v < count && !done; v += kBatch) {
             XY q[kBatch];
 #pragma unroll
             for (int k = 0; k < kBatch; ++k) q[k] = txy[first + (v + k) * step];
-            bool hit[kBatch];
+            unsigned inc[kBatch];
 #pragma unroll
             for (int k = 0; k < kBatch; ++k) {
               const double dx = q[k].x - xi, dy = q[k].y - yi;
-              hit[k] = dx * dx + dy * dy <= w.t_nbr && window(q[k].x, xi) == 2 && v + k < count;
+              const bool hit = (dx * dx + dy * dy <= w.t_nbr) & (window(q[k].x, xi) == 2) & (v + k < count);
+              inc[k] = hit ? kRow : 0u;
             }
             const double dxl = q[kBatch - 1].x - xi;
             const bool stop = step > 0 ? dxl > dstop : dxl < -dstop;
 #pragma unroll
-            for (int k = 0; k < kBatch; ++k) {
-              if (hit[k] && lp != lend) {  // trim (:91-93)
-                *lp = (unsigned short)(first + (v + k) * step);
-                lp += kTileW + 2;
-              }
+            for (int k = 0; k < kBatch; ++k) {  // trim (:91-93): a full list writes its spare row
+              *(unsigned short*)(lbase + lo) = (unsigned short)(first + (v + k) * step);
+              lo = min(lo + inc[k], lend);
             }
-            done = stop || lp == lend;
+            done = stop | (lo == lend);
           }
         } else {
           const int lane = t & 63, wave0 = t & ~63;
@@ -226,19 +229,19 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
 #ifdef SC_STAMPS
               ++dbg_stagings;
 #endif
-              constexpr int kPer = CAP / kTileW;
+              constexpr int kPer = (CAP + kTileW - 1) / kTileW;  // (CAP need not be a multiple of the tile width)
               XY r[kPer];
 #pragma unroll
               for (int k = 0; k < kPer; ++k) {
                 const int slot = rws + t + k * kTileW;
-                if (slot < total) {
+                if (slot < total && t + k * kTileW < CAP) {
                   const int j = tile_index(tl, slot);
                   r[k] = XY{x[j], y[j]};
                 }
               }
 #pragma unroll
               for (int k = 0; k < kPer; ++k)
-                if (rws + t + k * kTileW < total) txy[t + k * kTileW] = r[k];
+                if (rws + t + k * kTileW < total && t + k * kTileW < CAP) txy[t + k * kTileW] = r[k];
               __syncthreads();
             }
             SC_CLOCK(dbg_t_stage);
@@ -363,7 +366,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       // reverse edges from the previous strip
       scan(live && C < kMaxNbr, tl.n0 + tl.n1 + (em - 1 - tl.a2), em - bm, -1,
            [&](double xj, double xq) { return !(xq <= xj + w.d) ? 0 : (xq >= xj - w.d ? 2 : 1); });
-      if constexpr (LDS) C = (int)(lp - &list[0][t]) / (kTileW + 2);
+      if constexpr (LDS) C = (int)((lo - lo0) / kRow);
 #ifdef SC_STAMPS
       SC_STAMP_VALUE(0, 12, dbg_rounds);
       SC_STAMP_VALUE(0, 13, dbg_stagings);
@@ -711,7 +714,7 @@ __global__ void __launch_bounds__(kTileW)
   constexpr int kPad = SC_SCAN_BATCH - 1;  // a batched scan may read this far past either end of the tile
   __shared__ XY txy_padded[CAP + 2 * kPad];
   XY* const txy = txy_padded + kPad;
-  __shared__ unsigned short list[kMaxNbr][kTileW + 2];  // tile slots of the neighbors, [slot][thread]
+  __shared__ unsigned short list[kMaxNbr + 1][kTileW + 2];  // tile slots of the neighbors, [slot][thread]; + a spare row (scan)
   __shared__ int wkey[6 * (kTileW / 64)];  // the windowed scans' round keys (2 per wave); the lists' reach per range (6 per wave)
 
   const int t = threadIdx.x;
@@ -772,7 +775,7 @@ __global__ void __launch_bounds__(kTileW)
 
   // 2. stage (x, y) of the three ranges; every load of the tile is in flight before the first LDS write
   if (in_lds) {
-    constexpr int kPer = CAP / kTileW;
+    constexpr int kPer = (CAP + kTileW - 1) / kTileW;
     XY r[kPer];
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
