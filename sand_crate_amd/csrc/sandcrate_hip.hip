@@ -1783,6 +1783,16 @@ int sc_debug_stamps(sc_ctx* c, long long* out) {
 }
 #endif
 
+#ifdef SC_TIMELINE
+// diagnostic build: [kTlKernels][65536][4] = (start, end) on the 100 MHz clock, HW_ID, XCC_ID of every wave of the last pass A / pass B
+int sc_debug_timeline(sc_ctx* c, long long* out) {
+  if (!c || !out) return fail(SC_ERR_ARG, "null argument");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(sc::g_timeline), sizeof(long long) * sc::kTlKernels * sc::kTlWaves * 4));
+  return SC_OK;
+}
+#endif
+
 // ---- timing -----------------------------------------------------------------------------------
 
 static int harvest(sc_ctx* c) {

@@ -297,6 +297,9 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
                                                        int* __restrict__ blockSums, int* __restrict__ blockOff,
                                                        int* __restrict__ counters, int* __restrict__ bigList,
                                                        volatile int* __restrict__ bigHint, int* __restrict__ bigTable) {
+#ifdef SC_TIMELINE
+  SC_TIMELINE_KERNEL((g_tl_epoch & 1) ? 7 : 2);
+#endif
   __shared__ int waveTot[kBlock / 64];
   __shared__ int last;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -434,6 +437,7 @@ __global__ void __launch_bounds__(kSortBlock)
     k_sort_big(const int* __restrict__ counters, const int* __restrict__ bigList, const int* __restrict__ bigTable,
                Buckets bk, double* __restrict__ keyX, int* __restrict__ keyId, int* __restrict__ perm, int* __restrict__ sortedStamp,
                int stamp) {
+  SC_TIMELINE_KERNEL(5);
   __shared__ int pre[kRankMaxBuckets + 1];  // tasks before bucket q (the scan built the table)
   __shared__ double ox[kSortChunk];         // the chunk's keys in bin order
   __shared__ int oid[kSortChunk];
@@ -648,6 +652,7 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ coun
                                                     int* __restrict__ perm, double* __restrict__ keyX,
                                                     int* __restrict__ keyId, int* __restrict__ keyCell, int cap,
                                                     int live_hint) {
+  SC_TIMELINE_KERNEL(3);
   int i = chunk_of_block(live_hint) * blockDim.x + threadIdx.x;
   const int ic = min(i, cap - 1);  // loads that do not depend on the stored count go out first
   int c = cellS[ic];
@@ -722,6 +727,7 @@ __global__ void __launch_bounds__(kReorderBlock)
               double* __restrict__ vxT, double* __restrict__ vyT, int* __restrict__ idT, int* __restrict__ cellT,
               int* __restrict__ wslotT, const int* __restrict__ sortedStamp, int stamp, int ncols,
               int* __restrict__ tileBounds, int live_hint) {
+  SC_TIMELINE_KERNEL(4);
   __shared__ double ckx[kRankChunk];
   __shared__ int cki[kRankChunk];
   __shared__ int wcell[kReorderBlock + 2 * kRankWindow];

@@ -718,6 +718,7 @@ __global__ void __launch_bounds__(kTileW)
   __shared__ int wkey[6 * (kTileW / 64)];  // the windowed scans' round keys (2 per wave); the lists' reach per range (6 per wave)
 
   const int t = threadIdx.x;
+  SC_TIMELINE_KERNEL(0);
   const int tile_id = tile_of_block_ends_first(tiles_expected(w));
   const int i0 = tile_id * kTileW;
   const int i = i0 + t;
@@ -1043,6 +1044,7 @@ __global__ void __launch_bounds__(kTileW)
   __shared__ double tP[kTileCapB];
 
   const int t = threadIdx.x;
+  SC_TIMELINE_KERNEL((w.tick & 1) ? 6 : 1);
   // part 1 / 2: the blocks with / without band particles only (halo overlap: two launches, the exchange starts
   // between them); 0: all blocks.  bandw > 0 (slabs of rows: the band blocks are the first and last of the sorted
   // order): part 1 is a launch of 2 bandw workgroups over the first and the last bandw blocks -- a small kernel
@@ -1101,6 +1103,9 @@ __global__ void __launch_bounds__(kTileW)
     counters[C_SUMC_HI] = 0;
     counters[C_MAXC] = 0;
     counters[C_NBIG] = 0;
+#ifdef SC_TIMELINE
+    g_tl_epoch = w.tick + 1;
+#endif
     progress[1] = w.tick + 1;  // host-mapped: the host keeps at most a few ticks of launches queued
     progress[2] = n;           // ... and sizes heuristics by a recent live count
   }
