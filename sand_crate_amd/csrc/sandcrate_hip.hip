@@ -334,6 +334,8 @@ int build_world(sc_ctx* c, World& w, const sc_params& p, int nseg, const Seg* se
     w.ncols = (int)(ccmax - ccmin + 1) + 2;
   }
   w.inv_d = 1.0 / w.d;
+  w.row0d = (double)w.row0;
+  w.col0d = (double)w.col0;
   w.eta_scale = (w.d * w.level) * (1.0 / 4294967296.0);
   w.eta_half = (w.d * w.level) * 0.5;
   w.k_ss = w.dt * w.ss;
@@ -380,8 +382,8 @@ int make_world(sc_ctx* c) {
 WallInputs wall_inputs_of(const World& w) {
   WallInputs k;
   std::memset(&k, 0, sizeof k);
-  k.r = w.r; k.d = w.d; k.lo = w.lo; k.hi = w.hi; k.t_wall = w.t_wall; k.touch_box = w.touch_box; k.far_box = w.far_box;
-  k.row0 = w.row0; k.col0 = w.col0; k.own_lo = w.own_lo; k.own_hi = w.own_hi;
+  k.r = w.r; k.d = w.d; k.inv_d = w.inv_d; k.lo = w.lo; k.hi = w.hi; k.t_wall = w.t_wall; k.touch_box = w.touch_box; k.far_box = w.far_box;
+  k.row0 = w.row0; k.col0 = w.col0; k.row0d = w.row0d; k.col0d = w.col0d; k.own_lo = w.own_lo; k.own_hi = w.own_hi;
   k.nrows = w.nrows; k.ncols = w.ncols; k.nseg = w.nseg; k.nbody = w.nbody; k.slab = w.slab; k.slab_axis = w.slab_axis;
   std::memcpy(k.seg, w.seg, sizeof k.seg);
   std::memcpy(k.body, w.body, sizeof k.body);

@@ -49,6 +49,7 @@ struct World {
   double ccd_skip2;  // squared step length below which `far` particles skip the crossing test
   // cell grid: row = floor(y/d) - row0, col = floor(x/d) - col0; ring of empty cells around it
   long long row0, col0;
+  double row0d, col0d;  // the same as float64 (exact: far below 2^53), for the cell index of K1
   int nrows, ncols;
   int nseg, nbody;
   int noise_mode;
@@ -72,7 +73,7 @@ struct World {
 // World that the fused epilogue of pass B needs for the NEXT tick (sc_set_next_inputs).  Field names
 // match World so that one template serves both.
 struct WallInputs {
-  double r, d, lo, hi, t_wall, touch_box, far_box;
+  double r, d, inv_d, lo, hi, t_wall, touch_box, far_box, row0d, col0d;
   long long row0, col0, own_lo, own_hi;
   int nrows, ncols, nseg, nbody, slab, slab_axis;
   Seg seg[kMaxSeg];
@@ -154,7 +155,7 @@ struct LaneRun {
 
 __device__ __forceinline__ LaneRun lane_run(int key) {
   const int lane = threadIdx.x & 63;
-  int prev = __shfl_up(key, 1, 64);
+  const int prev = __builtin_amdgcn_update_dpp(key, key, 0x138, 0xf, 0xf, false);  // wave_shr:1 (lane 0 keeps its own)
   bool is_head = lane == 0 || key != prev;
   unsigned long long heads = __ballot(is_head);  // every lane of the wave must call this
   unsigned long long below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));

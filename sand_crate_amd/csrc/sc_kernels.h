@@ -62,9 +62,23 @@ __global__ void k_bump(int* counters, int m, int reset, int next_id) {
 // (px, py).  W is World or WallInputs.  A particle in contact with a wall leaves its record at `rec` in the
 // tick's record buffer -- the caller passes the particle's own storage index, so that no shared counter
 // hands out slots (one returning atomic per wave on one address was the cost of a compact list).
+// floor(p / d) as the reference takes it (collision_detector.py:126: an IEEE division, then floor) without the division
+// wherever that is safe: p * (1/d) is within 3e-16 |q| of the quotient q, and so is the rounded division, so both have the
+// quotient's floor unless the product lies within that of an integer -- only then (one particle in 10^9) is the division
+// taken.  (Two float64 divisions per particle were a fifth of the vector instructions of the fused wall pass.)
+__device__ __forceinline__ double floor_div(double p, double d, double inv_d) {
+  const double q = p * inv_d;
+  double f = floor(q);
+  const double t = q - f, band = fabs(q) * 1e-12 + 1e-300;
+  if (!(t > band && t < 1.0 - band)) f = floor(p / d);  // also NaN / infinity
+  return f;
+}
+
+// `segs`: the segments to look at, a bit per segment, the same for every lane of the wave -- all of them, or (pass B's
+// epilogue) those near the block's particles; a segment outside the mask must be farther than far_box from this particle.
 template <class W>
 __device__ __forceinline__ int wall_and_cell(const W& w, double& px, double& py, int& wslot, int* __restrict__ counters,
-                                             int rec, double* __restrict__ wrec) {
+                                             int rec, double* __restrict__ wrec, unsigned segs = ~0u) {
   wslot = -1;
   if (px < w.lo || px > w.hi || py < w.lo || py > w.hi) return -1;  // crate.py:152 (dead ghosts carry x = +inf)
   bool ghost = false;
@@ -75,7 +89,8 @@ __device__ __forceinline__ int wall_and_cell(const W& w, double& px, double& py,
   // bounding-box reject (exact-safe: the boxes are inflated far beyond rounding error)
   unsigned cand = 0;
   bool far = true;
-  for (int k = 0; k < w.nseg; ++k) {
+  for (unsigned left = segs & (w.nseg >= 32 ? ~0u : (1u << w.nseg) - 1u); left; left &= left - 1) {
+    const int k = __builtin_ctz(left);
     Seg s = w.seg[k];
     double ox = fmax(fmax(fmin(s.ax, s.bx) - px, px - fmax(s.ax, s.bx)), 0.0);
     double oy = fmax(fmax(fmin(s.ay, s.by) - py, py - fmax(s.ay, s.by)), 0.0);
@@ -145,9 +160,11 @@ __device__ __forceinline__ int wall_and_cell(const W& w, double& px, double& py,
     atomicOr(&counters[C_FLAGS], F_NAN);
     return -1;
   }
-  double fr = floor(py / w.d), fc = floor(px / w.d);  // collision_detector.py:126
-  long long lr = (long long)fr - w.row0, lc = (long long)fc - w.col0;
-  if (!(fabs(fr) < 9e15) || !(fabs(fc) < 9e15) || lr < 1 || lr > w.nrows - 2 || lc < 1 || lc > w.ncols - 2) {
+  const double fr = floor_div(py, w.d, w.inv_d), fc = floor_div(px, w.d, w.inv_d);  // collision_detector.py:126
+  // row / column in the grid, taken in float64 (integers far below 2^53: exact) -- 64-bit integer conversions and
+  // compares are several instructions each; a NaN or an infinity fails the range test like any row outside the grid
+  const double lr = fr - w.row0d, lc = fc - w.col0d;
+  if (!(lr >= 1.0 && lr <= (double)(w.nrows - 2) && lc >= 1.0 && lc <= (double)(w.ncols - 2))) {
     if (!ghost) atomicOr(&counters[C_FLAGS], F_OUT_OF_GRID);  // a ghost beyond the local grid is simply not needed
     return -1;
   }
@@ -943,9 +960,14 @@ __device__ __forceinline__ void collider_noise(const World& w, uint64_t z, int s
   }
 }
 
-// r = p_i - (p_j + eta) of crate.py:167-171 from the difference (dx, dy) = p_i - p_j.  Float-tolerance math: no decision is taken on it.
-// Counter mode: eta = (hi32 - 2^31) * eta_scale, folded into one convert and one fused multiply-add per
-// component: r = (dx + 2^31 eta_scale) - u32 * eta_scale.
+// r = p_i - (p_j + eta) of crate.py:167-171 from the difference (dx, dy) = o_i - p_j, o_i = pair_origin(p_i).  Float-tolerance
+// math: no decision is taken on it.  Counter mode: eta = (hi32 - 2^31) * eta_scale, folded into one convert and one fused
+// multiply-add per component: r = ((p_i + 2^31 eta_scale) - p_j) - u32 * eta_scale, the bracket's first sum taken once per
+// particle (pair_origin) instead of once per pair.
+template <int NOISE>
+__device__ __forceinline__ double pair_origin(const World& w, double p) {
+  return NOISE == SC_NOISE_COUNTER ? p + w.eta_half : p;
+}
 template <int NOISE>
 __device__ __forceinline__ void pair_offset(const World& w, uint64_t z, int slot, const double* __restrict__ eta, int off,
                                             double dx, double dy, double& rx, double& ry) {
@@ -953,8 +975,8 @@ __device__ __forceinline__ void pair_offset(const World& w, uint64_t z, int slot
     z ^= z >> 32;
     z *= kMix;
     z ^= z >> 32;
-    rx = fma((double)(uint32_t)(z >> 32), -w.eta_scale, dx + w.eta_half);
-    ry = fma((double)(uint32_t)z, -w.eta_scale, dy + w.eta_half);
+    rx = fma((double)(uint32_t)(z >> 32), -w.eta_scale, dx);
+    ry = fma((double)(uint32_t)z, -w.eta_scale, dy);
   } else {
     double ex, ey;
     collider_noise<NOISE>(w, z, slot, eta, off, ex, ey);

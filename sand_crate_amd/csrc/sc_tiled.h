@@ -528,6 +528,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
     double sumc = 0, ax = 0, ay = 0;
     const int off = (NOISE == SC_NOISE_HOST) ? offById[idi] : 0;
     uint64_t z = noise_base(w.noise_key, idi);
+    const double ox = pair_origin<NOISE>(w, pi.x), oy = pair_origin<NOISE>(w, pi.y);
     constexpr int kFetch = LDS ? 1 : 4;  // global-memory tiles: four neighbors per round trip
     XY qq[kFetch];
 #if defined(SC_ABL_A_NOPAIRS)
@@ -541,13 +542,13 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       for (int s = 0; s < Cloop; ++s) {
         const XY q = txy[list[s][t]];
         double rx, ry;
-        pair_offset<NOISE>(w, z, s, eta, off, pi.x - q.x, pi.y - q.y, rx, ry);
+        pair_offset<NOISE>(w, z, s, eta, off, ox - q.x, oy - q.y, rx, ry);
         z += kGold;
         const double s2 = rx * rx + ry * ry;
         const double rinv = rsqrt_nr(s2);
         const double c = fmin(fmax(s2 * rinv * w.inv_d, 0.0), 1.0);
         sumc += c;
-        const double g = c * (1 - c) * rinv;
+        const double g = fma(-c, c, c) * rinv;
         ax += g * rx;
         ay += g * ry;
       }
@@ -570,13 +571,13 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       for (int k = 1; k < kFetch; ++k)
         if (s % kFetch == k) q = qq[k];
       double rx, ry;
-      pair_offset<NOISE>(w, z, s, eta, off, pi.x - q.x, pi.y - q.y, rx, ry);
+      pair_offset<NOISE>(w, z, s, eta, off, ox - q.x, oy - q.y, rx, ry);
       z += kGold;
       const double s2 = rx * rx + ry * ry;
       const double rinv = rsqrt_nr(s2);
       const double c = fmin(fmax(s2 * rinv * w.inv_d, 0.0), 1.0);  // crate.py:270: clip(dist / d, 0, 1)
       sumc += c;
-      const double g = c * (1 - c) * rinv;             // crate.py:342 with n = r / dist (:174)
+      const double g = fma(-c, c, c) * rinv;             // crate.py:342 with n = r / dist (:174)
       ax += g * rx;
       ay += g * ry;
     }
@@ -878,6 +879,7 @@ __device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl,
   xi = mp.x;
   yi = mp.y;
   const double sxi = ms.x, syi = ms.y;
+  const double ox = pair_origin<NOISE>(w, xi), oy = pair_origin<NOISE>(w, yi);
   const int off = (NOISE == SC_NOISE_HOST) ? offById[idi] : 0;
   const uint64_t zbase = noise_base(w.noise_key, idi);
   const double k_ss = w.k_ss, k_pp = w.k_pp, k_0 = w.k_0;
@@ -889,7 +891,7 @@ __device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl,
       double oP;
       load(js[s], op, os, oP);
       double rx, ry;
-      pair_offset<NOISE>(w, zbase + (uint64_t)s * kGold, s, eta, off, xi - op.x, yi - op.y, rx, ry);
+      pair_offset<NOISE>(w, zbase + (uint64_t)s * kGold, s, eta, off, ox - op.x, oy - op.y, rx, ry);
       const double rinv = rsqrt_nr(rx * rx + ry * ry);
       const double dot = ((sxi - os.x) * rx + (syi - os.y) * ry) * rinv;  // (s_i - s_j) . n_ij
       const double wr = fma(dot, k_ss, fma(Pi + oP, k_pp, k_0)) * rinv;
@@ -917,7 +919,7 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
                                               const double* __restrict__ vy, const double* __restrict__ wrec,
                                               const PairSums ps, const double xi, const double yi, const double Pi,
                                               double vxi, double vyi, double& xn, double& yn, double& vxn, double& vyn,
-                                              double (&mon)[kMonPhases]) {
+                                              double (&mon)[kMonPhases], const unsigned near_now = ~0u) {
   auto norm2 = [](double a, double b) { return sqrt(a * a + b * b); };
   double ux = 0, uy = 0;
 #pragma unroll
@@ -988,7 +990,11 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
     const double bx = xi + mx, by = yi + my;    // crate.py:183-184
     const double abx = bx - xi, aby = by - yi;  // geometry_utils.py:205 uses (b - a)
     double fac = 1.0;
+    // (the lanes that are here move less than 2 d -- then only the segments near the block can be crossed -- or the
+    // wave looks at every segment)
+    const unsigned segs = __ballot(!(mx * mx + my * my < w.ccd_skip2)) ? ~0u : near_now;
     for (int mm = 0; mm < 2 * w.nseg; ++mm) {
+      if (!(segs >> (mm < w.nseg ? mm : mm - w.nseg) & 1u)) continue;  // the padded twins of segment k: k and nseg + k
       const Seg s = w.pad[mm];
       const double dcx = s.bx - s.ax, dcy = s.by - s.ay;
       if (!(dcy * abx + (-dcx) * aby < 0)) continue;  // opposite_direction_map (:205)
@@ -1023,6 +1029,10 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
 // GROUP: the fused cell count groups scrambled waves by cell (sc_kernels.h: count_cells); launched while big buckets exist
 // BANDED: the instantiation the halo overlap launches with slabs of rows (a window of band blocks, parts 1 and 3 below);
 // kept out of the default kernel, where its branches cost 0.8 us per tick in scalar registers
+// (diagnostic build: the stamps of even and odd ticks go to different buffers, so that the last tick of a run -- which has
+// no look-ahead -- does not overwrite the tick before it)
+#define SC_STAMP_B(slot) SC_STAMP((w.tick & 1) ? 2 : 1, slot)
+#define SC_STAMP_VALUE_B(slot, value) SC_STAMP_VALUE((w.tick & 1) ? 2 : 1, slot, value)
 template <int NOISE, bool FUSED, bool MON = false, bool GROUP = false, bool BANDED = false>
 __global__ void __launch_bounds__(kTileW)
     k_pass_b(World w, int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
@@ -1081,7 +1091,7 @@ __global__ void __launch_bounds__(kTileW)
   }
   const int i0 = tile_id * kTileW;
   const int i = i0 + t;
-  SC_STAMP(1, 0);
+  SC_STAMP_B(0);
   // 1. one round trip: the three ranges (published by pass A for this very block), the particle's
   // scalars and all twenty table entries -- none of these loads waits for another
   const int ic = min(i, cap - 1);
@@ -1121,9 +1131,26 @@ __global__ void __launch_bounds__(kTileW)
   } else if (BANDED && part == 3) {
     late_block = !window_block;
   }
-  SC_STAMP(1, 1);
+  SC_STAMP_B(1);
   const int m = min(kTileW, n - i0);
   const bool live = t < m;
+  // Which wall segments can a particle of this block have to do with?  The block is a run of the (row, x) order: its
+  // start-of-tick positions lie in the box spanned by its first and last particle (one strip: between their x; more:
+  // the full width; in y within a cell height of their y), and lane k holds segment k's distance to that box -- one pass
+  // for all segments instead of a loop over them per particle.  Two masks, a bit per segment, the same in every lane:
+  //   near_now   this tick's segments within far_box of the box: the only ones a particle that moves less than 2 d can
+  //              cross (pass_b_finish; far_box = r + 2 d is what `wslot == -1` already stands for, per particle);
+  //   near_next  the next tick's segments within far_box + kMove of the box: the only ones the look-ahead wall pass has to
+  //              look at for a particle that moved less than kMove = 2 d (19 of 20 blocks have none: the loop over the
+  //              segments was most of the 2.4 us that epilogue added to a wave's 8.4).
+  // The loads are requested here; the masks are formed behind the tile's loads, before the barrier.
+  const int ilast = i0 + m - 1;
+  const int cell_first = cell[i0], cell_last = cell[ilast];
+  const double x_first = x[i0], x_last = x[ilast], y_first = y[i0], y_last = y[ilast];
+  const int seg_k = min(t & 63, kMaxSeg - 1);
+  const Seg seg_now = w.seg[seg_k];
+  Seg seg_next{0, 0, 0, 0};
+  if (FUSED) seg_next = wn.seg[seg_k];
 
   Tile tl;
   tl.a0 = tb0;
@@ -1138,8 +1165,8 @@ __global__ void __launch_bounds__(kTileW)
     for (int s = 0; s < kMaxNbr; ++s) js[s] = nbr[(size_t)s * cap + ic];
   }
   const bool in_lds = total <= kTileCapB;
-  SC_STAMP_VALUE(1, 10, total);
-  SC_STAMP_VALUE(1, 11, tile_id);
+  SC_STAMP_VALUE_B(10, total);
+  SC_STAMP_VALUE_B(11, tile_id);
   const bool ghost = w.slab && (cpacked & kGhostBit);
 #if defined(SC_ABL_B_NOPAIRS)
   const int C = 0;
@@ -1180,20 +1207,40 @@ __global__ void __launch_bounds__(kTileW)
       }
     }
   }
+  unsigned near_now, near_next = ~0u;
+  const double kMove = 2 * w.d;
+  {
+    // one strip: the last particle's cell is less than a row of cells after the first one's and its x is not smaller
+    // (in a later strip either the cell is a row further or the column -- hence x -- is smaller)
+    const bool one_strip = (cell_last & kCellMask) - (cell_first & kCellMask) < w.ncols && x_last >= x_first;
+    const double bx0 = one_strip ? x_first : w.lo, bx1 = one_strip ? x_last : w.hi;
+    const double by0 = y_first - w.d, by1 = y_last + w.d;
+    auto box_gap = [&](const Seg& sg, double& ox, double& oy) {
+      ox = fmax(fmax(fmin(sg.ax, sg.bx) - bx1, bx0 - fmax(sg.ax, sg.bx)), 0.0);
+      oy = fmax(fmax(fmin(sg.ay, sg.by) - by1, by0 - fmax(sg.ay, sg.by)), 0.0);
+    };
+    double ox, oy;
+    box_gap(seg_now, ox, oy);
+    near_now = (unsigned)__ballot((t & 63) < w.nseg && ox <= w.far_box && oy <= w.far_box);
+    if (FUSED) {
+      box_gap(seg_next, ox, oy);
+      near_next = (unsigned)__ballot((t & 63) < wn.nseg && ox <= wn.far_box + kMove && oy <= wn.far_box + kMove);
+    }
+  }
   __syncthreads();
 
-  SC_STAMP(1, 2);
+  SC_STAMP_B(2);
   // 3-4. pair math and epilogue; ghosts and lanes without a particle skip it
   double mon[kMonPhases] = {0, 0, 0, 0, 0, 0};
   double xn = __builtin_huge_val(), yn = 0.0, vxn = 0.0, vyn = 0.0;  // a ghost's copy: +inf makes the next
   int idn = -1;                                                        // removal test (crate.py:152) drop it
   const bool active = live && !ghost;
   const int self = i - tl.a0;
+  double xi = 0, yi = 0, Pi = 0;  // the particle's start-of-tick position and its pressure
   if (in_lds) {
     PairSums ps{0, 0, 0, 0};
-    double xi = 0, yi = 0, Pi = 0;
     if (active) ps = pass_b_pairs<NOISE, true, MON>(w, tl, txy, tss, tP, self, Cn, idi, js, x, y, eta, offById, P, sx, sy, xi, yi, Pi);
-    SC_STAMP(1, 3);
+    SC_STAMP_B(3);
     __syncthreads();  // everybody is done with (x, y): the array now takes the velocities
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
@@ -1201,18 +1248,17 @@ __global__ void __launch_bounds__(kTileW)
       if (s < total) txy[s] = rv[k];
     }
     __syncthreads();
-    SC_STAMP(1, 4);
+    SC_STAMP_B(4);
     if (active) {
       idn = idi;
-      pass_b_finish<true, MON>(w, tl, txy, C, Cn, ws, js, vx, vy, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn, mon);
+      pass_b_finish<true, MON>(w, tl, txy, C, Cn, ws, js, vx, vy, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn, mon, near_now);
     }
   } else if (active) {
-    double xi, yi, Pi;
     idn = idi;
     const PairSums ps = pass_b_pairs<NOISE, false, MON>(w, tl, txy, tss, tP, self, Cn, idi, js, x, y, eta, offById, P, sx, sy, xi, yi, Pi);
-    pass_b_finish<false, MON>(w, tl, txy, C, Cn, ws, js, vx, vy, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn, mon);
+    pass_b_finish<false, MON>(w, tl, txy, C, Cn, ws, js, vx, vy, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn, mon, near_now);
   }
-  SC_STAMP(1, 5);
+  SC_STAMP_B(5);
   if constexpr (MON) {  // sums over the wave, one atomic per wave and phase; [kMonPhases] counts the particles
     double cnt = active ? 1.0 : 0.0;
 #pragma unroll
@@ -1226,19 +1272,27 @@ __global__ void __launch_bounds__(kTileW)
   if (FUSED) {
     int cnext = -1, wsn = -1;
     const double xp = xn, yp = yn;  // as integrated: what a halo message carries (the receiver runs its own K1)
-    if (active) cnext = wall_and_cell(wn, xn, yn, wsn, counters, i, wrec_next);
+    // the next tick's segments near this block (near_next), or all of them when some particle moved further than that
+    // mask allows for
+    const bool strayed = active && !(fabs(xn - xi) <= kMove && fabs(yn - yi) <= kMove);
+    const unsigned segs = __ballot(strayed) ? ~0u : near_next;
+    SC_STAMP_B(16);
+    if (active) cnext = wall_and_cell(wn, xn, yn, wsn, counters, i, wrec_next, segs);
+    SC_STAMP_B(17);
     if (live) {
       cellS[i] = cnext;
       if (cnext >= 0) wslotS[i] = wsn;
     }
+    SC_STAMP_B(18);
     count_cells<GROUP>(cnext, cellCount);  // every lane of the wave takes part
+    SC_STAMP_B(19);
     // slabs: the coming tick's halo message is packed here too (same rule and same pre-wall-fix position as
     // k_halo_pack); a workgroup-uniform branch, every lane of the wave takes part
     if (wn.slab && haloL)
       packed = halo_pack_one(active, xp, yp, vxn, vyn, idn, wn.d, wn.slab_axis, w.own_lo, w.own_hi, w.halo, w.has_left,
                              w.has_right, haloL, haloR, haloCap, counters, late_block);
   }
-  SC_STAMP(1, 6);
+  SC_STAMP_B(6);
   if (live) {
     xo[i] = xn;
     yo[i] = yn;
@@ -1246,7 +1300,7 @@ __global__ void __launch_bounds__(kTileW)
     vyo[i] = vyn;
     ido[i] = idn;
   }
-  SC_STAMP(1, 7);
+  SC_STAMP_B(7);
   if (BANDED && window_block) {  // part 3: this window block is done; the halo records it wrote become visible device-wide
     const int wrote = __syncthreads_or(packed);
     if (t == 0) {
