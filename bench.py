@@ -51,15 +51,19 @@ TICK_BYTES = 244
 FORCE_BYTES = 128
 
 
+def latest_profile(pattern: str):
+    """The newest round's committed profile matching profiles/<pattern> (r03_... before r02_...), or None."""
+    found = sorted((ROOT / "profiles").glob(pattern), reverse=True)
+    return found[0] if found else None
+
+
 def measured_traffic(particles_per_gpu: int, kernel: str):
     """HBM-side bytes per launch of `kernel` from the rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
     separate runs, calibrated on a float64 copy: scripts/collect_traffic.sh -> profiles/r01_traffic_<N>.json).
     bench.py cannot collect hardware counters itself; it reports the committed measurement of the same
     workload, or None when there is none for this size."""
-    path = ROOT / "profiles" / f"r02_traffic_{particles_per_gpu}.json"
-    if not path.exists():
-        path = ROOT / "profiles" / f"r01_traffic_{particles_per_gpu}.json"
-    if not path.exists():
+    path = latest_profile(f"r*_traffic_{particles_per_gpu}.json")
+    if path is None:
         return None, None
     data = json.loads(path.read_text())
     k = data["kernels"].get(kernel)
@@ -128,8 +132,8 @@ def fp64_issue(particles_per_gpu: int, kernels: dict):
     """VALU issue roofline of the force pair from the committed SQ counters (profiles/r02_sq_<N>.json, written by
     scripts/collect_sq.sh on the same workload): wave-instructions issued per launch against what 1,024 SIMDs can
     issue in the measured kernel time.  None when no counter file exists for this size."""
-    path = ROOT / "profiles" / f"r02_sq_{particles_per_gpu}.json"
-    if not path.exists():
+    path = latest_profile(f"r*_sq_{particles_per_gpu}.json")
+    if path is None:
         return None
     data = json.loads(path.read_text())
     out = {"source": f"profiles/{path.name}: {data.get('source', '')}", "simds": 1024, "clock_GHz": 2.4}
@@ -145,29 +149,22 @@ def fp64_issue(particles_per_gpu: int, kernels: dict):
 
 
 def rocprof_pair(particles_per_gpu: int):
-    """The force pair by the committed rocprofv3 summary of this very command (profiles/r02_kernel_stats_1m.csv, written
-    by scripts/profile_round.sh): the profiler's average kernel durations carry no event overhead (the HIP events of
-    the live measurement add ~2 us per kernel).  The profiler runs are taken without the clock warm-up of the live
-    measurement (--clock-warmup 0: under the profiler the second context's one-time queue set-up, 17-28 ms, lands inside
-    one kernel's duration and spoils the average), so their kernels run ~3 % slower than the live figure.  None for other
-    sizes."""
-    path = ROOT / "profiles" / "r02_kernel_stats_1m.csv"
-    if particles_per_gpu != 1048576 or not path.exists():
+    """The force pair by the committed rocprofv3 kernel trace of this very command (scripts/profile_round.sh ->
+    scripts/summarize_trace.py -> profiles/rNN_kernel_calls_<particles>.json): per-call means over the calls with the
+    workload's grid only -- the --stats CSV of the same run averages the 4,096-particle launches of the primer below
+    into pass B.  The profiler's durations carry no event overhead (the HIP events of the live measurement add ~2 us per
+    kernel); the profiler runs are taken without the clock warm-up of the live measurement (--clock-warmup 0: under the
+    profiler the second context's one-time queue set-up lands inside one kernel's duration).  None when no summary is
+    committed for this size."""
+    path = latest_profile(f"r*_kernel_calls_{particles_per_gpu}.json")
+    if path is None:
         return None
-    import csv
-    best = {}
-    with open(path) as f:
-        for row in csv.DictReader(f):
-            for key, tag in (("pass_a", "k_pass_a<"), ("pass_b", "k_pass_b<")):
-                if tag in row["Name"] and int(row["Calls"]) > best.get(key, (0, 0.0))[0]:  # the steady-state instantiation
-                    best[key] = (int(row["Calls"]), float(row["AverageNs"]) / 1000.0)
-    if len(best) != 2:
+    pair = json.loads(path.read_text()).get("pair")
+    if not pair:
         return None
-    us = best["pass_a"][1] + best["pass_b"][1]
-    gbps = FORCE_BYTES * particles_per_gpu / (us * 1e-6) / 1e9
-    return {"source": f"profiles/{path.name} (rocprofv3 --kernel-trace --stats of this command with --clock-warmup 0)", "pass_a_us": round(best["pass_a"][1], 2),
-            "pass_b_us": round(best["pass_b"][1], 2), "avg_launch_us": round(us, 2), "achieved_GBps": round(gbps, 1),
-            "frac": round(gbps / HBM_PEAK_GBPS, 5)}
+    return {"source": f"profiles/{path.name} (rocprofv3 --kernel-trace of this command with --clock-warmup 0, per-call means, primer left out)",
+            "pass_a_us": pair["pass_a_us"], "pass_b_us": pair["pass_b_us"], "avg_launch_us": pair["avg_launch_us"],
+            "achieved_GBps": pair["achieved_GBps"], "frac": pair["frac"]}
 
 
 def regimes(make_sim, settle, per_gpu: int):
@@ -187,6 +184,10 @@ def regimes(make_sim, settle, per_gpu: int):
         done = upto
     total = sum(out[k]["ms_per_step"] * n for k, n in (("ticks_5_24_uniform", 20), ("ticks_25_104", 80)))
     out["ticks_5_104"] = {"ms_per_step": round(total / 100.0, 5), "particle_steps_per_s": round(per_gpu * 100.0 / (total / 1000.0), 1)}
+    # the sustained figure: everything after the warm-up steps of this one run, pile-up regime included
+    spans = (("ticks_5_24_uniform", 20), ("ticks_25_104", 80), ("ticks_105_124", 20), ("ticks_125_424", 300), ("ticks_425_474_pile_up", 50))
+    total = sum(out[k]["ms_per_step"] * n for k, n in spans)
+    out["sustained_ticks_5_474"] = {"ms_per_step": round(total / 470.0, 5), "particle_steps_per_s": round(per_gpu * 470.0 / (total / 1000.0), 1)}
     del out["ticks_0_4_warmup"]
     return out
 

@@ -4,15 +4,18 @@
 # bench line, rocprofv3 kernel stats of the same command, fabric traffic (PMC), SQ counters.  Outputs land in
 # gpurun_out/<tag>_*; copy what is to be judged into profiles/.
 export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 N=${2:-1048576}
 mkdir -p gpurun_out
 python bench.py --particles $N > gpurun_out/${TAG}_bench_$N.json 2> gpurun_out/${TAG}_bench_$N.err || tail -5 gpurun_out/${TAG}_bench_$N.err
 rm -rf gpurun_out/${TAG}_stats_$N
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats_$N -- python bench.py --particles $N --cpu-sample 0 --no-kernel-events --repeats 1 --clock-warmup 0 > gpurun_out/${TAG}_stats_$N.log 2>&1 || tail -5 gpurun_out/${TAG}_stats_$N.log
 cp gpurun_out/${TAG}_stats_$N/*/*kernel_stats.csv gpurun_out/${TAG}_kernel_stats_$N.csv 2>/dev/null
+# per-call durations of the workload's launches only (the --stats CSV averages the primer's launches in): what
+# bench.py reports as roofline.rocprof
+python scripts/summarize_trace.py gpurun_out/${TAG}_stats_$N gpurun_out/${TAG}_kernel_calls_$N.json $N > gpurun_out/${TAG}_kernel_calls_$N.log 2>&1 || tail -3 gpurun_out/${TAG}_kernel_calls_$N.log
 scripts/collect_traffic.sh $N > gpurun_out/${TAG}_traffic_$N.log 2>&1 || tail -5 gpurun_out/${TAG}_traffic_$N.log
-cp profiles/r02_traffic_$N.json gpurun_out/ 2>/dev/null
+cp profiles/${TAG}_traffic_$N.json gpurun_out/ 2>/dev/null
 scripts/collect_sq.sh $N > gpurun_out/${TAG}_sq_$N.log 2>&1 || tail -5 gpurun_out/${TAG}_sq_$N.log
-cp profiles/r02_sq_$N.json gpurun_out/ 2>/dev/null
-tail -c 600 gpurun_out/${TAG}_bench_$N.json; echo; head -12 gpurun_out/${TAG}_kernel_stats_$N.csv; tail -12 gpurun_out/${TAG}_traffic_$N.log; tail -8 gpurun_out/${TAG}_sq_$N.log
+cp profiles/${TAG}_sq_$N.json gpurun_out/ 2>/dev/null
+tail -c 600 gpurun_out/${TAG}_bench_$N.json; echo; tail -14 gpurun_out/${TAG}_kernel_calls_$N.log; tail -12 gpurun_out/${TAG}_traffic_$N.log; tail -8 gpurun_out/${TAG}_sq_$N.log

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the counter CSVs of scripts/collect_sq.sh into profiles/r02_sq_<N>.json: per kernel, the average of every
+"""Turns the counter CSVs of scripts/collect_sq.sh into profiles/r03_sq_<N>.json: per kernel, the average of every
 counter per launch (summed over the chip, as rocprofv3 reports it)."""
 import collections
 import csv
@@ -32,7 +32,7 @@ res = {"particles": n, "instantiations": {name: k for name, (k, _) in picked.ite
        "source": "rocprofv3 --kernel-trace --pmc <4 SQ counters per pass>, bench.py --steps 20 --warmup 5 --repeats 1; "
                  "average per launch, summed over the chip; SQ_ACTIVE_* / SQ_WAVE_CYCLES / SQ_WAIT_* in quad-cycles",
        "kernels": {k: {c: agg[k][c] / cnt[k][c] for c in sorted(agg[k])} for k in sorted(agg)}}
-path = f"profiles/r02_sq_{n}.json"
+path = f"profiles/r03_sq_{n}.json"
 json.dump(res, open(path, "w"), indent=1)
 for k, v in res["kernels"].items():
     if "SQ_INSTS_VALU" not in v:
