@@ -9,8 +9,9 @@ name, ``editable_coefficients()``, ``debug_arrows``, ``debug_prints``, ``tick``,
 
 What runs where
 ---------------
-host   particle sources (particle_source.py), rigid-body motion (rigid_body.py), pad_segments:
-       O(new particles) and O(S) per tick, and they own the global NumPy RNG stream.
+host   rigid-body motion (rigid_body.py) and pad_segments: O(S) per tick.  (The particle sources draw on the device --
+       sc_emit_particles, below; particle_source.py's host path remains for noise="host-sync", which also keeps the
+       global NumPy RNG stream on the host.)
 GPU    everything per particle: removal, wall contacts + hard wall fix, strip sort and neighbor
        lists, pressure / tension / gravity / viscosity / wall bounce / continuous collision,
        integration (sand_crate_amd/csrc/sc_kernels.h).  State stays on the device; the
@@ -194,6 +195,13 @@ class Crate:
             self._host_rng_mark = (key.copy(), pos)
 
     def _fall_back_to_host_stream(self) -> None:
+        """A particle source whose flow * dt exceeds 30 takes the BTPE branch of NumPy's legacy binomial
+        (particle_source.py:18), which the device does not have (sc_rng.h holds the inversion branch): from here on the
+        host draws the stream -- same numbers, but two synchronisations per tick.  Said out loud, once."""
+        import warnings
+        warnings.warn("sand_crate_amd: a particle source draws binomial(n, p) with n * p > 30 -- that branch of NumPy's legacy "
+                      "binomial is not on the device; physics_tick() falls back to noise='host-sync' (identical results, two "
+                      "host synchronisations per tick) for the rest of this run", RuntimeWarning, stacklevel=3)
         self.sync_host_rng()
         self._noise = "host-sync"
 
@@ -311,7 +319,9 @@ class Crate:
         arrays = {"particles": snap["particles"], "velocities": snap["velocities"], "ids": snap["ids"]}
         if pressure is not None and len(pressure) == len(snap["ids"]):
             arrays["pressure"] = pressure
-        if snap["rng"] is not None:
+        # the stream to restore is the one the run draws from: the device's in noise mode "host", else the host's (a crate
+        # that fell back from "host" to "host-sync" still has a -- stale -- device state: it is not written)
+        if snap["rng"] is not None and meta["noise"] == "host":
             arrays["rng_key"] = snap["rng"][0]
             meta["rng_pos"] = int(snap["rng"][1])
         np.savez(path, meta=np.array(json.dumps(meta)), **arrays)
@@ -347,7 +357,7 @@ class Crate:
         crate.tick = meta["tick"]
         crate._count, crate._count_known = n, True
         crate._cache = (arrays["particles"], arrays["velocities"], arrays.get("pressure", np.zeros(n)))
-        if "rng_key" in arrays:
+        if meta["noise"] == "host" and "rng_key" in arrays:
             eng.rng_set_state(arrays["rng_key"], meta["rng_pos"])
         elif meta["host_rng"] is not None:
             h = meta["host_rng"]

@@ -120,6 +120,7 @@ struct sc_ctx {
   // host-mapped progress block written by the GPU, read by the host without synchronisation:
   // [0] big buckets seen by the last finished scan, [1] ticks finished, [2] live particles of that tick,
   // [4 + 4 (tick % kHaloRing) ..]: halo record counts of that tick (sent left / right, received left / right)
+  int64_t emit_most = 0;  // the largest per-call bound of emitted particles so far (sc_emit_particles)
   int* bigHintHost = nullptr;
   int* bigHintDev = nullptr;
   bool force_rank_big = false;
@@ -1397,7 +1398,8 @@ static int ensure_side_stream(sc_ctx* c) {
   if (!c->side_stream) HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
   // (device-side ordering only: without the system-scope fence an event between two kernels costs ~1 us instead of ~10)
   if (!c->ev_band) HIPCHK(hipEventCreateWithFlags(&c->ev_band, hipEventDisableTiming | hipEventDisableSystemFence));
-  if (!c->ev_xchg) HIPCHK(hipEventCreateWithFlags(&c->ev_xchg, hipEventDisableTiming | hipEventDisableSystemFence));
+  // (ev_xchg orders halo buffers that a peer GPU wrote: it keeps the system-scope fence)
+  if (!c->ev_xchg) HIPCHK(hipEventCreateWithFlags(&c->ev_xchg, hipEventDisableTiming));
   return SC_OK;
 }
 
@@ -1587,14 +1589,21 @@ int sc_checkpoint_begin(sc_ctx* c) {
   if (c->in_step) return fail(SC_ERR_STATE, "sc_checkpoint_begin inside a tick");
   if (c->snap_pending) return fail(SC_ERR_STATE, "a checkpoint is already under way: sc_checkpoint_finish first");
   HIPCHK(hipSetDevice(c->device));
-  if (!c->side_stream) {
-    HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c->snap_ready, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->snap_done, hipEventDisableTiming));
-    HIPCHK(hipHostMalloc((void**)&c->snap_counters_h, C_COUNT * sizeof(int), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&c->snap_rng_h, sizeof(RngState), hipHostMallocDefault));
-    HIPCHK(dalloc(&c->snap_rng_d, 1));
+  // After a promised tick the storage arrays already hold the coming tick's removal and wall fix while its cell
+  // indices and bucket counts live in buffers a snapshot does not take: a restore would run that wall pass a second
+  // time, on fixed positions.  (Crate.run / physics_tick never leave a promise pending between calls.)
+  if (c->prebinned)
+    return fail(SC_ERR_STATE, "sc_checkpoint_begin after sc_set_next_inputs promised the next tick: run that tick first");
+  // the side stream may exist already (halo overlap creates it): every snapshot resource is created on its own
+  {
+    const int rc = ensure_side_stream(c);
+    if (rc) return rc;
   }
+  if (!c->snap_ready) HIPCHK(hipEventCreateWithFlags(&c->snap_ready, hipEventDisableTiming));
+  if (!c->snap_done) HIPCHK(hipEventCreateWithFlags(&c->snap_done, hipEventDisableTiming));
+  if (!c->snap_counters_h) HIPCHK(hipHostMalloc((void**)&c->snap_counters_h, C_COUNT * sizeof(int), hipHostMallocDefault));
+  if (!c->snap_rng_h) HIPCHK(hipHostMalloc((void**)&c->snap_rng_h, sizeof(RngState), hipHostMallocDefault));
+  if (!c->snap_rng_d) HIPCHK(dalloc(&c->snap_rng_d, 1));
   const int64_t n = launch_bound(c);  // a host-side bound of the stored count; the exact count travels with the copy
   if (n > c->snapAlloc) {
     HIPCHK(hipStreamSynchronize(c->side_stream));
@@ -1761,6 +1770,14 @@ int sc_emit_particles(sc_ctx* c, const sc_source* sources, int32_t n_sources, do
     if (rc) return rc;
     upper = std::min<int64_t>(h[C_NS] + most, std::max<int64_t>(max_particles, h[C_NS]));
     if (upper > c->cap) return fail(SC_ERR_CAPACITY, "%lld particles may exceed the context capacity %lld", (long long)upper, (long long)c->cap);
+  }
+  // The host's id counter is a bound too (the device hands out the real ids): every call adds the binomial's restart
+  // bound, several times the particles actually emitted, and the id tables of SC_NOISE_HOST are sized and scanned by
+  // it every tick.  The count the device published with a recent tick pulls it back, like `upper` above.
+  c->emit_most = std::max(c->emit_most, most);
+  if (done > c->live_hint_from && c->tick >= done && c->tick - done <= 8) {
+    const int64_t published_ids = *(volatile int*)(c->bigHintHost + 3);
+    if (published_ids > 0) c->next_id = std::min(c->next_id, published_ids + (c->tick - done + 1) * c->emit_most);
   }
   if (c->next_id + most > std::numeric_limits<int>::max()) return fail(SC_ERR_CAPACITY, "particle ids exhausted");
   HIPCHK(hipSetDevice(c->device));

@@ -235,64 +235,6 @@ __device__ __forceinline__ int wave_max(int v) {
   return v;
 }
 
-// Diagnostic build only (-DSC_STAMPS): per-wave clock stamps at phase boundaries, drained (s_waitcnt 0) so that a
-// stamp means "everything before is done".  The stamps go to a buffer no kernel reads (sc_debug_stamps reads it
-// on the host); the product build compiles none of this.
-#ifdef SC_STAMPS
-constexpr int kStampSlots = 24, kStampWaves = 1 << 16;
-constexpr int kStampKernels = 3;  // 0: pass A, 1: pass B, 2: k_sort_big
-__device__ long long g_stamps[kStampKernels][kStampWaves][kStampSlots];
-#define SC_STAMP(kernel, slot)                                                                          \
-  do {                                                                                                   \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                         \
-    const long long now_ = __builtin_amdgcn_s_memtime();                                                 \
-    const int wv_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                                 \
-    if ((threadIdx.x & 63) == 0 && wv_ < kStampWaves) g_stamps[kernel][wv_][slot] = now_;                \
-  } while (0)
-#define SC_STAMP_VALUE(kernel, slot, value)                                                             \
-  do {                                                                                                   \
-    const int wv_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                                 \
-    if ((threadIdx.x & 63) == 0 && wv_ < kStampWaves) g_stamps[kernel][wv_][slot] = (value);             \
-  } while (0)
-#define SC_CLOCK(acc)                                                                                    \
-  do {                                                                                                   \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                         \
-    const long long now_ = __builtin_amdgcn_s_memtime();                                                 \
-    acc += now_ - dbg_last;                                                                              \
-    dbg_last = now_;                                                                                     \
-  } while (0)
-#else
-#define SC_STAMP(kernel, slot) do { } while (0)
-#define SC_STAMP_VALUE(kernel, slot, value) do { } while (0)
-#define SC_CLOCK(acc) do { } while (0)
-#endif
-
-// Diagnostic build only (-DSC_TIMELINE): when and where every wave of pass A / pass B ran -- start and end on the 100 MHz
-// constant clock (the same on every XCD) and the hardware slot (HW_ID: wave, SIMD, CU, SE; XCC_ID) -- so that the host can
-// draw the occupancy of every CU over the kernel (scripts/timeline.py).  Two clock reads and one 32-byte store per wave.
-#ifdef SC_TIMELINE
-// 0: pass A, 1: pass B, 2: scan, 3: scatter, 4: reorder, 5: sort_big; 6, 7: pass B and scan of odd ticks (so that the gap from one
-// tick's pass B to the next tick's scan can be read off: g_tl_epoch = the tick pass B last started, published by its tile 0)
-constexpr int kTlWaves = 1 << 16, kTlKernels = 8;
-__device__ int g_tl_epoch;
-__device__ long long g_timeline[kTlKernels][kTlWaves][4];
-struct TimelineGuard {  // records at every exit of the kernel (the destructor runs on each return path)
-  int kernel;
-  long long t0;
-  __device__ __forceinline__ explicit TimelineGuard(int k) : kernel(k), t0(__builtin_amdgcn_s_memrealtime()) {}
-  __device__ __forceinline__ ~TimelineGuard() {
-    const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if ((threadIdx.x & 63) == 0 && wv < kTlWaves) {
-      g_timeline[kernel][wv][0] = t0;
-      g_timeline[kernel][wv][1] = __builtin_amdgcn_s_memrealtime();
-      g_timeline[kernel][wv][2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
-      g_timeline[kernel][wv][3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
-    }
-  }
-};
-#define SC_TIMELINE_KERNEL(kernel) sc::TimelineGuard timeline_guard_(kernel)
-#else
-#define SC_TIMELINE_KERNEL(kernel) do { } while (0)
-#endif
-
 }  // namespace sc
+
+#include "sc_diag.h"

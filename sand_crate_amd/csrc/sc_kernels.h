@@ -314,9 +314,7 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
                                                        int* __restrict__ blockSums, int* __restrict__ blockOff,
                                                        int* __restrict__ counters, int* __restrict__ bigList,
                                                        volatile int* __restrict__ bigHint, int* __restrict__ bigTable) {
-#ifdef SC_TIMELINE
-  SC_TIMELINE_KERNEL((g_tl_epoch & 1) ? 7 : 2);
-#endif
+  SC_TIMELINE_SCAN();
   __shared__ int waveTot[kBlock / 64];
   __shared__ int last;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -625,16 +623,7 @@ __global__ void __launch_bounds__(kSortBlock)
         perm[b + s0 + r] = pm[u];
       }
     }
-#ifdef SC_STAMPS
-    {
-      int big = 0;
-#pragma unroll
-      for (int u = 0; u < kPerT; ++u)
-        if (tid + u * kSortBlock < len) big = max(big, hist[bin[u] + 1] - hist[bin[u]]);
-      for (int o = 32; o > 0; o >>= 1) big = max(big, __shfl_xor(big, o, 64));
-      SC_STAMP_VALUE(2, 9, big);
-    }
-#endif
+    SC_STAMP_LARGEST_BIN();
     SC_STAMP(2, 6);
     if (local == 0 && tid == 0) sortedStamp[bigList[q]] = stamp;
   }

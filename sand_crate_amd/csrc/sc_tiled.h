@@ -136,11 +136,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
   const int self = i - tl.a0;
   XY pi = {0.0, 0.0};
   if (live) pi = load_xy(self);
-#ifdef SC_ABL_A_NOENUM
-  if (false) {
-#else
-  if (ENUM) {
-#endif
+  if (ENUM && !diag::kNoSearch) {
     if (slots_fit && (LDS ? live : true)) {
       const double xi = pi.x, yi = pi.y;
       // One scan: `count` candidates from tile slot `first`, walking by `step`, examined one by one in
@@ -157,11 +153,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       //   by the whole wave, 64 candidates per step, hits ranked by lane = scan order.  Every
       //   particle still sees its candidates in the reference's order, so the lists are the same.
       constexpr int kHalf = CAP / 2, kSerial = 32;
-#ifdef SC_STAMPS
-      long long dbg_rounds = 0, dbg_stagings = 0, dbg_wants = 0, dbg_coop = 0;
-      long long dbg_t_round = 0, dbg_t_stage = 0, dbg_t_serial = 0, dbg_t_coop = 0, dbg_t_other = 0, dbg_last = __builtin_amdgcn_s_memtime();
-      int dbg_scan = 0;
-#endif
+      WindowProbe probe;  // (diagnostic builds only: sc_diag.h)
       const double dstop = w.d * (1.0 + 0x1p-20);
       // next free entry of this thread's list (LDS tiles) as a byte offset into `list`; row kMaxNbr is a spare one that
       // takes the writes of a full list, so that an append is a store and a clamped add -- no branch
@@ -204,10 +196,8 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
         } else {
           const int lane = t & 63, wave0 = t & ~63;
           int pos = first, left = want ? count : 0;
-#ifdef SC_STAMPS
-          dbg_wants |= (long long)__popcll(__ballot(left > 0)) << (8 * dbg_scan++);
-#endif
-          SC_CLOCK(dbg_t_other);
+          probe.scan_begins(left);
+          probe.clock_other();
           for (;;) {
             // the unfinished position that is furthest behind, block-wide (keys double-buffered by round)
             const int key = wave_min_all(left > 0 ? pos * step : INT_MAX);
@@ -219,16 +209,12 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
 #pragma unroll
             for (int k = 1; k < kTileW / 64; ++k) k0 = min(k0, wk[k]);
             if (k0 == INT_MAX) break;  // uniform: nobody has candidates left in this range
-#ifdef SC_STAMPS
-            ++dbg_rounds;
-#endif
+            probe.round();
             const int p0 = k0 * step;
-            SC_CLOCK(dbg_t_round);
+            probe.clock_round();
             if ((unsigned)(p0 - rws) >= (unsigned)CAP) {  // not in the resident window: stage the one around it
               rws = step > 0 ? (p0 / kHalf) * kHalf : max(0, (p0 / kHalf - 1) * kHalf);
-#ifdef SC_STAMPS
-              ++dbg_stagings;
-#endif
+              probe.staging();
               constexpr int kPer = (CAP + kTileW - 1) / kTileW;  // (CAP need not be a multiple of the tile width)
               XY r[kPer];
 #pragma unroll
@@ -244,7 +230,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
                 if (rws + t + k * kTileW < total && t + k * kTileW < CAP) txy[t + k * kTileW] = r[k];
               __syncthreads();
             }
-            SC_CLOCK(dbg_t_stage);
+            probe.clock_stage();
             const int ws = rws;
             auto inside = [&](int p) { return (unsigned)(p - ws) < (unsigned)CAP; };
             // kWinBatch candidates per iteration, their LDS reads issued together (a dependent read per candidate made
@@ -272,12 +258,10 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
               pos += nv * step;
               left = over ? 0 : left - nv;
             }
-            SC_CLOCK(dbg_t_serial);
+            probe.clock_serial();
             unsigned long long m = __ballot(left > 0 && inside(pos));
             while (m) {
-#ifdef SC_STAMPS
-              ++dbg_coop;
-#endif
+              probe.turn();
               // the owner's state is read with v_readlane (the owner is wave-uniform): no LDS round trips on the way
               const int owner = __builtin_amdgcn_readfirstlane(__ffsll(m) - 1);
               auto of = [&](int v) { return __builtin_amdgcn_readlane(v, owner); };
@@ -339,27 +323,20 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
               }
               m = __ballot(left > 0 && inside(pos));
             }
-            SC_CLOCK(dbg_t_coop);
+            probe.clock_coop();
           }
-          SC_CLOCK(dbg_t_round);
+          probe.clock_round();
         }
       };
       // same strip, after i: x_j <= x_i + d                                  (:106-109)
       scan(live, self + 1, e0 - (i + 1), 1, [&](double xj, double xq) { return xj > xq + w.d ? 0 : 2; });
       SC_STAMP(0, 3);
-#ifdef SC_STAMPS
-      int dbg_c1 = C;
-      for (int o = 32; o > 0; o >>= 1) dbg_c1 += __shfl_xor(dbg_c1, o, 64);
-#endif
+      probe.hits_after_first(C);
       // next strip: x_i - d <= x_j <= x_i + d                                (:112-119)
       scan(live && C < kMaxNbr, tl.n0 + (b1 - tl.a1), e1 - b1, 1,
            [&](double xj, double xq) { return xj > xq + w.d ? 0 : (xj >= xq - w.d ? 2 : 1); });
       SC_STAMP(0, 4);
-#ifdef SC_STAMPS
-      int dbg_c2 = C;
-      for (int o = 32; o > 0; o >>= 1) dbg_c2 += __shfl_xor(dbg_c2, o, 64);
-      SC_STAMP_VALUE(0, 9, (long long)dbg_c1 | ((long long)dbg_c2 << 32));
-#endif
+      probe.hits_after_second(C);
       // reverse edges (:85-88): i is a forward candidate of j, same strip
       scan(live && C < kMaxNbr, self - 1, i - b0, -1, [&](double xj, double xq) { return !(xq <= xj + w.d) ? 0 : 2; });
       SC_STAMP(0, 5);
@@ -367,17 +344,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       scan(live && C < kMaxNbr, tl.n0 + tl.n1 + (em - 1 - tl.a2), em - bm, -1,
            [&](double xj, double xq) { return !(xq <= xj + w.d) ? 0 : (xq >= xj - w.d ? 2 : 1); });
       if constexpr (LDS) C = (int)((lo - lo0) / kRow);
-#ifdef SC_STAMPS
-      SC_STAMP_VALUE(0, 12, dbg_rounds);
-      SC_STAMP_VALUE(0, 13, dbg_stagings);
-      SC_STAMP_VALUE(0, 14, dbg_wants);
-      SC_STAMP_VALUE(0, 15, dbg_coop);
-      SC_STAMP_VALUE(0, 16, dbg_t_round);
-      SC_STAMP_VALUE(0, 17, dbg_t_stage);
-      SC_STAMP_VALUE(0, 18, dbg_t_serial);
-      SC_STAMP_VALUE(0, 19, dbg_t_coop);
-      SC_STAMP_VALUE(0, 20, dbg_t_other);
-#endif
+      probe.flush();
     } else if (live) {
       // a tile beyond 65535 particles (a block inside one gigantic bucket) cannot use u16 slots:
       // entries go straight to the table as -(index+1); correctness path only
@@ -420,9 +387,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       for (int s = 0; s < C; ++s) list[s][t] = nbr16[(size_t)s * cap + i];
   }
 
-#ifdef SC_ABL_A_NOENUM
-  C = 0;
-#endif
+  if (diag::kNoSearch) C = 0;
   SC_STAMP(0, 6);
   // 3b. The table's slots refer to the ranges published in tileBoundsT -- for the usual tile the candidate ranges.  A
   // tile whose candidate ranges exceed pass B's LDS budget (a block in or beside a pile: thousands of candidates,
@@ -531,13 +496,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
     const double ox = pair_origin<NOISE>(w, pi.x), oy = pair_origin<NOISE>(w, pi.y);
     constexpr int kFetch = LDS ? 1 : 4;  // global-memory tiles: four neighbors per round trip
     XY qq[kFetch];
-#if defined(SC_ABL_A_NOPAIRS)
-    const int Cloop = 0;
-#elif defined(SC_ABL_CAPC)
-    const int Cloop = min(C, SC_ABL_CAPC);
-#else
-    const int Cloop = C;
-#endif
+    const int Cloop = diag::pairs_a(C);
     if (STAGE && !LDS && staged) {  // the neighbors are in the staged reach: an LDS tile's loop
       for (int s = 0; s < Cloop; ++s) {
         const XY q = txy[list[s][t]];
@@ -588,96 +547,26 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
 
   SC_STAMP(0, 7);
   // 5. lists out, slot-major: for a fixed slot consecutive threads write consecutive words.
-  // The table's slots refer to the ranges published in tileBoundsT -- for the usual tile the candidate ranges.  A
-  // tile whose candidate ranges exceed pass B's LDS budget (a block in or beside a pile: thousands of candidates,
-  // of which the lists name a few hundred) publishes the ranges its lists actually reach instead -- per range from
-  // the lowest to the highest slot named, the block's own particles included -- and renumbers its entries, so that
-  // pass B stages these tiles in LDS like any other instead of gathering every neighbor from global memory.
-  if constexpr (STAGE && !LDS) {
+  // The table's slots refer to the ranges published in tileBoundsT -- for the usual tile the candidate ranges, for a tile
+  // whose candidate ranges exceed pass B's LDS budget the reach of its lists, the entries renumbered (3b above).
+  if (ENUM) {
     int nb[6] = {tl.a0, tl.a0 + tl.n0, tl.a1, tl.a1 + tl.n1, tl.a2, tl.a2 + tl.n2}, sub[3] = {0, 0, 0};
-    if (strim) reach(nb, sub);
+    const bool trim = slots_fit && total > kTileCapB;  // uniform over the workgroup
+    if (trim) {
+      if (!(STAGE && !LDS)) extremes();  // (a tile that staged its reach for the pair math has them in wkey already)
+      reach(nb, sub);
+    }
     if (t == 0) {
       int* tbT = tileBoundsT + 6 * tile_id;
       tbT[0] = nb[0]; tbT[1] = nb[1]; tbT[2] = nb[2]; tbT[3] = nb[3]; tbT[4] = nb[4]; tbT[5] = nb[5];
     }
     if (live) {
+      C = min(C, kMaxNbr);  // (never more by construction; the rows of the table end there)
       if (slots_fit) {
-        if (strim && !staged) {
+        if (trim && !staged) {
           for (int s = 0; s < C; ++s) {
             const int e = list[s][t];
             nbr16[(size_t)s * cap + i] = (unsigned short)(e - (e < sr1 ? sub[0] : e < sr2 ? sub[1] : sub[2]));
-          }
-        } else {
-          for (int s = 0; s < C; ++s) nbr16[(size_t)s * cap + i] = list[s][t];
-        }
-      }
-      cnt[i] = (unsigned char)C;
-    }
-  } else
-  if (ENUM) {
-    int nb0 = tl.a0, nb1 = tl.a0 + tl.n0, nb2 = tl.a1, nb3 = tl.a1 + tl.n1, nb4 = tl.a2, nb5 = tl.a2 + tl.n2;
-    const int r1 = tl.n0, r2 = tl.n0 + tl.n1;  // first slot of the next rows' / previous rows' range
-    int sub0 = 0, sub1 = 0, sub2 = 0;          // what renumbering takes off an entry of each range
-    const bool trim = slots_fit && total > kTileCapB;  // uniform over the workgroup
-    if (trim) {
-      int lo0 = live ? self : INT_MAX, hi0 = live ? self : -1, lo1 = INT_MAX, hi1 = -1, lo2 = INT_MAX, hi2 = -1;
-      if (live)
-        for (int s = 0; s < C; ++s) {
-          const int e = list[s][t];
-          if (e < r1) {
-            lo0 = min(lo0, e);
-            hi0 = max(hi0, e);
-          } else if (e < r2) {
-            lo1 = min(lo1, e);
-            hi1 = max(hi1, e);
-          } else {
-            lo2 = min(lo2, e);
-            hi2 = max(hi2, e);
-          }
-        }
-      lo0 = wave_min_all(lo0);
-      hi0 = wave_max_all(hi0);
-      lo1 = wave_min_all(lo1);
-      hi1 = wave_max_all(hi1);
-      lo2 = wave_min_all(lo2);
-      hi2 = wave_max_all(hi2);
-      __syncthreads();  // the scans are done with wkey
-      if ((t & 63) == 0) {
-        int* wk = wkey + 6 * (t >> 6);
-        wk[0] = lo0; wk[1] = hi0; wk[2] = lo1; wk[3] = hi1; wk[4] = lo2; wk[5] = hi2;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < kTileW / 64; ++k) {
-        const int* wk = wkey + 6 * k;
-        lo0 = min(lo0, wk[0]); hi0 = max(hi0, wk[1]);
-        lo1 = min(lo1, wk[2]); hi1 = max(hi1, wk[3]);
-        lo2 = min(lo2, wk[4]); hi2 = max(hi2, wk[5]);
-      }
-      const int m0 = hi0 - lo0 + 1;  // never empty: the block's own particles
-      const int m1 = hi1 >= lo1 ? hi1 - lo1 + 1 : 0, m2 = hi2 >= lo2 ? hi2 - lo2 + 1 : 0;
-      if (m1 == 0) lo1 = r1;
-      if (m2 == 0) lo2 = r2;
-      nb0 = tl.a0 + lo0;
-      nb1 = nb0 + m0;
-      nb2 = tl.a1 + (lo1 - r1);
-      nb3 = nb2 + m1;
-      nb4 = tl.a2 + (lo2 - r2);
-      nb5 = nb4 + m2;
-      sub0 = lo0;
-      sub1 = lo1 - m0;
-      sub2 = lo2 - m0 - m1;
-    }
-    if (t == 0) {
-      int* tbT = tileBoundsT + 6 * tile_id;
-      tbT[0] = nb0; tbT[1] = nb1; tbT[2] = nb2; tbT[3] = nb3; tbT[4] = nb4; tbT[5] = nb5;
-    }
-    if (live) {
-      if (slots_fit) {
-        if (trim) {
-          for (int s = 0; s < C; ++s) {
-            const int e = list[s][t];
-            nbr16[(size_t)s * cap + i] = (unsigned short)(e - (e < r1 ? sub0 : e < r2 ? sub1 : sub2));
           }
         } else {
           for (int s = 0; s < C; ++s) nbr16[(size_t)s * cap + i] = list[s][t];
@@ -1113,11 +1002,10 @@ __global__ void __launch_bounds__(kTileW)
     counters[C_SUMC_HI] = 0;
     counters[C_MAXC] = 0;
     counters[C_NBIG] = 0;
-#ifdef SC_TIMELINE
-    g_tl_epoch = w.tick + 1;
-#endif
+    SC_TIMELINE_EPOCH(w.tick + 1);
     progress[1] = w.tick + 1;  // host-mapped: the host keeps at most a few ticks of launches queued
     progress[2] = n;           // ... and sizes heuristics by a recent live count
+    progress[3] = counters[C_NEXT_ID];  // ... and keeps its bound of the ids handed out near the device's count (sc_emit_particles)
   }
   if (BANDED && part == 3 && n == 0 && blockIdx.x == 0 && t == 0)  // nothing at all: nobody else would publish the epoch
     __hip_atomic_store(&counters[C_BAND_FLAG], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1168,13 +1056,7 @@ __global__ void __launch_bounds__(kTileW)
   SC_STAMP_VALUE_B(10, total);
   SC_STAMP_VALUE_B(11, tile_id);
   const bool ghost = w.slab && (cpacked & kGhostBit);
-#if defined(SC_ABL_B_NOPAIRS)
-  const int C = 0;
-#elif defined(SC_ABL_CAPC)
-  const int C = live ? min(Craw, SC_ABL_CAPC) : 0;
-#else
-  const int C = live ? Craw : 0;
-#endif
+  const int C = live ? diag::pairs_b(Craw) : 0;
   const int Cn = ghost ? 0 : C;  // ghosts serve as neighbors only
   const int ws = live ? ws_raw : -1;
 
