@@ -219,6 +219,9 @@ int sc_set_slab(sc_ctx* ctx, int64_t col_lo, int64_t col_hi, int32_t halo, int32
  * sc_set_slab; results do not depend on the axis. */
 int sc_set_slab_axis(sc_ctx* ctx, int32_t axis);
 int sc_upload_state_ids(sc_ctx* ctx, const double* xy, const double* vxy, const int64_t* ids, int64_t n);
+/* crate.py:138-147 under slabs: every rank draws the same new particles (same host stream) and appends the ones whose
+ * column / row it owns, under their global ids. */
+int sc_append_particles_ids(sc_ctx* ctx, const double* xy, const double* vxy, const int64_t* ids, int64_t n);
 int sc_halo_pack(sc_ctx* ctx, double* dev_left, double* dev_right, int64_t capacity_records);
 /* Message sizes.  A message need not carry the whole buffer: sc_halo_sizes gives, for the exchange of the coming
  * tick, the number of records (after the header record) to send to / receive from each side -- the count the same

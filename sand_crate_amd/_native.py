@@ -94,6 +94,7 @@ SIGNATURES = {
     "sc_set_slab_axis": (C.c_int, [_P, C.c_int32]),
     "sc_set_band_flag": (C.c_int, [_P, C.c_int]),
     "sc_upload_state_ids": (C.c_int, [_P, _D, _D, _I64, C.c_int64]),
+    "sc_append_particles_ids": (C.c_int, [_P, _D, _D, _I64, C.c_int64]),
     "sc_halo_pack": (C.c_int, [_P, _P, _P, C.c_int64]),
     "sc_halo_sizes": (C.c_int, [_P, C.c_int64, _I64, _I64, _I64, _I64]),
     "sc_halo_unpack": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64]),

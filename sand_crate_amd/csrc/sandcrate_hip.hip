@@ -452,12 +452,12 @@ int put_particles(sc_ctx* c, const double* xy, const double* vxy, int64_t n, boo
     }
     Bracket br(c, K_APPEND);
     hipLaunchKernelGGL(k_append, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, c->stage_xy, c->stage_vxy, (int)n,
-                       (int)c->next_id, dev_ids, c->counters, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], reset ? 1 : 0);
+                       (int)c->next_id, dev_ids, c->counters, c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], reset ? 1 : 0, (int)c->cap);
   }
   c->upper = base + n;
   c->next_id += n;
   c->live_hint_from = c->tick;  // counts published by earlier ticks do not include these particles
-  hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, c->stream, c->counters, (int)n, reset ? 1 : 0, (int)c->next_id);
+  hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, c->stream, c->counters, (int)n, reset ? 1 : 0, (int)c->next_id, (int)c->cap);
   HIPCHK(hipGetLastError());
   return SC_OK;
 }
@@ -1343,6 +1343,12 @@ int sc_upload_state_ids(sc_ctx* c, const double* xy, const double* vxy, const in
   if (!c || (n > 0 && !ids)) return fail(SC_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(c->device));
   return put_particles(c, xy, vxy, n, true, ids);
+}
+
+int sc_append_particles_ids(sc_ctx* c, const double* xy, const double* vxy, const int64_t* ids, int64_t n) {
+  if (!c || (n > 0 && !ids)) return fail(SC_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(c->device));
+  return put_particles(c, xy, vxy, n, false, ids);
 }
 
 int sc_halo_pack(sc_ctx* c, double* dev_left, double* dev_right, int64_t cap_records) {

@@ -27,10 +27,12 @@ __device__ __forceinline__ double closest_on_segment(const Seg& s, double px, do
 // ------------------------------------------------------------------------------------------
 __global__ void k_append(const double* __restrict__ xy, const double* __restrict__ vxy, int m, int first_id,
                          const int* __restrict__ ids, int* __restrict__ counters, double* __restrict__ x, double* __restrict__ y,
-                         double* __restrict__ vx, double* __restrict__ vy, int* __restrict__ id, int reset) {
+                         double* __restrict__ vx, double* __restrict__ vy, int* __restrict__ id, int reset, int cap) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   int base = reset ? 0 : counters[C_NS];
-  if (k < m) {
+  // (the host checks its own bound of the stored count; a slab also stores ghosts the host does not count)
+  if (k < m && base + k >= cap) atomicOr(&counters[C_FLAGS], F_CAPACITY);
+  if (k < m && base + k < cap) {
     x[base + k] = xy[2 * k];
     y[base + k] = xy[2 * k + 1];
     vx[base + k] = vxy[2 * k];
@@ -41,8 +43,8 @@ __global__ void k_append(const double* __restrict__ xy, const double* __restrict
   // separate one-thread launch (k_bump) ordered after this kernel on the stream.
 }
 
-__global__ void k_bump(int* counters, int m, int reset, int next_id) {
-  counters[C_NS] = (reset ? 0 : counters[C_NS]) + m;
+__global__ void k_bump(int* counters, int m, int reset, int next_id, int cap) {
+  counters[C_NS] = min((reset ? 0 : counters[C_NS]) + m, cap);
   counters[C_NEXT_ID] = next_id;  // the host's id counter after this append (an upper bound once the device emits)
 }
 

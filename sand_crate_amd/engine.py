@@ -93,6 +93,13 @@ class Engine:
             raise ValueError("particles, velocities and ids must have one row per particle")
         N.check(self._lib.sc_upload_state_ids(self._ctx, N.dptr(p), N.dptr(v), N.i64ptr(i), len(p)))
 
+    def append_with_ids(self, particles, velocities, ids) -> None:
+        p, v = N.f64(particles).reshape(-1, 2), N.f64(velocities).reshape(-1, 2)
+        i = np.ascontiguousarray(ids, dtype=np.int64).reshape(-1)
+        if not (len(p) == len(v) == len(i)):
+            raise ValueError("particles, velocities and ids must have one row per particle")
+        N.check(self._lib.sc_append_particles_ids(self._ctx, N.dptr(p), N.dptr(v), N.i64ptr(i), len(p)))
+
     def append(self, particles, velocities) -> None:
         p, v = N.f64(particles).reshape(-1, 2), N.f64(velocities).reshape(-1, 2)
         N.check(self._lib.sc_append_particles(self._ctx, N.dptr(p), N.dptr(v), len(p)))

@@ -42,6 +42,7 @@ import os
 import numpy as np
 
 from .crate import _NOISE_MODES, _TICK_COEFFICIENTS, tick_geometry
+from .particle_source import build_particle_sources
 from .rigid_body import build_rigid_bodies
 
 HALO_COLUMNS = 3
@@ -120,6 +121,20 @@ def rebalanced_cuts(hist: np.ndarray, col0: int, slabs: list[tuple[int, int]], b
     return [(bounds[k], bounds[k + 1]) for k in range(n)]
 
 
+def draw_new_particles(sources, tick: int, dt: float, max_particles: int, count: int):
+    """crate.py:138-147: the active sources in order, each seeing the count the previous one left (the draws come from the
+    global NumPy stream: binomial, rand, rand per source -- particle_source.py:17-24).  -> [(positions, velocities), ...]"""
+    out = []
+    for source in sources:
+        if source.active_ticks <= tick:
+            continue
+        new_p, new_v = source.generate_particles(dt=dt, max_particles=max_particles - count)
+        if new_p is not None:
+            out.append((new_p, new_v))
+            count += len(new_p)
+    return out
+
+
 class HipSlabBackend:
     """The compute side of one slab on one GPU: an `Engine` in slab mode plus halo buffers held as
     torch tensors (device memory and stream plumbing only)."""
@@ -151,6 +166,9 @@ class HipSlabBackend:
 
     def load(self, particles, velocities, ids) -> None:
         self.engine.upload_with_ids(particles, velocities, ids)
+
+    def append(self, particles, velocities, ids) -> None:
+        self.engine.append_with_ids(particles, velocities, ids)
 
     def set_axis(self, axis: int) -> None:
         self.engine.set_slab_axis(axis)
@@ -254,8 +272,12 @@ class SlabCrate:
         self.rebalances = 0
         self.world_config = world_config
         self.rigid_bodies = build_rigid_bodies(world_config.rigid_bodies)
-        if world_config.particle_sources:
-            raise ValueError("SlabCrate runs the update only; particle sources stay with the single-GPU Crate")
+        # crate.py:138-147 under slabs: every rank draws the SAME new particles from the same host stream (np.random,
+        # seeded like crate.py:22) and keeps the ones it owns, under their global ids -- what the single-domain `Crate`
+        # does in its counter / none noise modes, so slabs reproduce it bit for bit (see `_emit`)
+        self.particle_sources = build_particle_sources(world_config.particle_sources)
+        if self.particle_sources and not hasattr(backend if backend is not None else HipSlabBackend, "append"):
+            raise ValueError("this backend cannot append particles: particle sources need one that can")
         for name, value in world_config.coefficients.items():
             setattr(self, name, value)
         self.gravity = np.array(world_config.coefficients["gravity"], dtype=np.float64)
@@ -269,7 +291,8 @@ class SlabCrate:
             raise ValueError("axis must be 'x' (slabs of columns) or 'y' (slabs of rows)")
         self.axis = axis
         cols = column_of(p[:, 1 if axis == "y" else 0], d)
-        self.slabs = partition_columns(cols, self.world)
+        # (a scene that starts empty -- the YAML scenes do, their sources fill them -- is cut into equal widths of the box)
+        self.slabs = partition_columns(cols if len(cols) else np.arange(0, int(math.ceil(1.0 / d)) + 1, dtype=np.int64), self.world)
         if cuts is not None:  # the caller's cut columns instead of the equal-count ones
             if len(cuts) != self.world - 1 or any(b - a < 2 * HALO_COLUMNS + 2 for a, b in zip(cuts[:-1], cuts[1:])):
                 raise ValueError("cuts: world - 1 increasing columns, at least 2 * halo + 2 apart")
@@ -293,6 +316,9 @@ class SlabCrate:
             self.backend.set_axis(1 if axis == "y" else 0)
         self.backend.set_slab(self.lo, self.hi, HALO_COLUMNS, self.left is not None, self.right is not None)
         self._own_mask = own
+        self._next_id = len(p)  # ids are global: every rank numbers the emitted particles alike
+        if self.particle_sources and not self._chained:
+            np.random.seed(0)   # crate.py:22 (a chain seeds once, for all its members)
         self.backend.load(p[own], v[own], ids)
         self.halo_capacity = int(halo_capacity)
         if overlap is None:  # by default only where a particle may cross many cells per tick and still be packed in time
@@ -344,6 +370,9 @@ class SlabCrate:
         self._pad_cache = {}
         self.tick = 0
         self._now = None
+        self._next_id = len(p)
+        if self.particle_sources and not self._chained:
+            np.random.seed(0)
         if self.slabs != self._initial_slabs:
             self._apply_cuts(self._initial_slabs)
         own = self._own_mask
@@ -528,14 +557,38 @@ class SlabCrate:
         self._now = nxt
 
     def _may_promise(self, k: int, n_ticks: int) -> bool:
-        # a tick that re-balances packs its message itself, after the cuts are known: its predecessor must not
-        return k + 1 < n_ticks and not self._rebalance_due(self.tick + 1)
+        # a tick that re-balances packs its message itself, after the cuts are known: its predecessor must not; nor must
+        # the predecessor of a tick that emits particles (they belong into that tick's halo message)
+        return k + 1 < n_ticks and not self._rebalance_due(self.tick + 1) and not self._sources_active(self.tick + 1)
+
+    def _sources_active(self, tick: int) -> bool:
+        return any(src.active_ticks > tick for src in self.particle_sources)
+
+    def _emit(self, drawn=None) -> None:
+        """create_new_particles (crate.py:138-147), first thing in a tick: per active source `generate_particles` with the
+        room left under max_particles -- the GLOBAL count, one all-reduce per emitting tick -- drawn identically on every
+        rank; a rank appends the particles whose column (row) it owns.  `drawn`: the particles a `SlabChain` drew for all
+        its members."""
+        if not self._sources_active(self.tick):
+            return
+        if drawn is None:
+            drawn = draw_new_particles(self.particle_sources, self.tick, self.dt, int(self.max_particles),
+                                       self.global_particle_count())
+        d = self.particle_radius * 2
+        for new_p, new_v in drawn:
+            ids = self._next_id + np.arange(len(new_p), dtype=np.int64)
+            self._next_id += len(new_p)
+            col = column_of(new_p[:, 1 if self.axis == "y" else 0], d)
+            own = (col >= self.lo) & (col < self.hi)
+            if own.any():
+                self.backend.append(new_p[own], new_v[own], ids[own])
 
     def run(self, n_ticks: int) -> None:
         if self._chained:
             raise RuntimeError("a chain member is stepped by its SlabChain")
         for k in range(n_ticks):
-            self._begin_tick()
+            self._begin_tick()  # (first: the count the emission needs is taken on the coming tick's grid)
+            self._emit()
             self._pack(whole_messages=self._rebalance())
             self._exchange()
             self._end_tick(self._may_promise(k, n_ticks))
@@ -597,6 +650,8 @@ class SlabChain:
                                           rebalance_every=rebalance_every, cuts=cuts, overlap=overlap, rank=k,
                                           world=n_slabs, backend=backend, axis=axis, band_flag=band_flag))
         self.tick = 0
+        if self.members[0].particle_sources:
+            np.random.seed(0)  # crate.py:22
         self.message_records = []  # per tick: the records every message carried (left-to-right, then right-to-left)
 
     @property
@@ -635,6 +690,11 @@ class SlabChain:
         for k in range(n_ticks):
             for m in ms:
                 m._begin_tick()
+            if ms[0]._sources_active(ms[0].tick):  # one draw for all members (they share this process's np.random)
+                drawn = draw_new_particles(ms[0].particle_sources, ms[0].tick, ms[0].dt, int(ms[0].max_particles),
+                                           sum(self.owned_counts()))
+                for m in ms:
+                    m._emit(drawn)
             changed = False
             if ms[0]._rebalance_due(ms[0].tick):
                 col0, ncols = ms[0]._histogram_window()

@@ -23,8 +23,13 @@ class OracleSlabBackend:
         self.pressure = np.zeros(0)
 
     def load(self, particles, velocities, ids):
-        self.p, self.v, self.ids = particles.copy(), velocities.copy(), ids.copy()
+        self.p, self.v, self.ids = particles.copy().reshape(-1, 2), velocities.copy().reshape(-1, 2), ids.copy()
         self.pressure = np.zeros(len(ids))
+
+    def append(self, particles, velocities, ids):
+        self.p = np.vstack((self.p, particles))
+        self.v = np.vstack((self.v, velocities))
+        self.ids = np.concatenate((self.ids, np.asarray(ids, dtype=np.int64)))
 
     def set_axis(self, axis):
         self.axis = int(axis)

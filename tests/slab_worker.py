@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--rebalance-every", type=int, default=0)
     ap.add_argument("--skew", type=float, default=1.0, help="x -> x ** skew: more particles on the left")
     ap.add_argument("--axis", default="x", choices=["x", "y"], help="slabs of columns (x) or of rows (y)")
+    ap.add_argument("--scene", default="", help="a YAML scene as shipped (its particle sources included), started empty")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     import torch.distributed as dist
@@ -47,6 +48,10 @@ def main():
     from sand_crate_amd.slab import SlabCrate
     dist.init_process_group("gloo")
     wc, p, v = synthetic_world(a.particles, 0.1 if a.noise == "counter" else 0.0, a.vel, margin=a.margin, skew=a.skew)
+    if a.scene:
+        import sand_crate_amd as sc
+        wc = sc.load_config(ROOT / "config" / a.scene).world_config
+        p, v = np.zeros((0, 2)), np.zeros((0, 2))
     backend = None
     if a.backend == "oracle":
         from slab_oracle_backend import OracleSlabBackend

@@ -288,17 +288,18 @@ def bench_like_crate(sc, n, noise="counter"):
     return crate, wc, p, v, d
 
 
-def test_full_size_tick_matches_oracle(sc):
-    """BASELINE.json configs[1] (262,144 particles, bench.py's exact inputs): two ticks against the
-    vectorised oracle started from the same state."""
+@pytest.mark.parametrize("n,ticks", [(262144, 2), (1048576, 1)])
+def test_full_size_tick_matches_oracle(sc, n, ticks):
+    """BASELINE.json configs[1] and configs[2] -- 262,144 and 1,048,576 particles, bench.py's exact inputs, counter noise
+    (the headline configuration): ticks against the vectorised oracle started from the same state, every float
+    compared."""
     from oracle.scene import OracleCrate
     from oracle.tick import counter_noise_key, counter_noise_u01, tick_core
     from oracle.world import World
-    n = 262144
     crate, wc, p, v, d = bench_like_crate(sc, n)
     orc = OracleCrate(World(wc.rigid_bodies, [], dict(wc.coefficients)))
     ids = np.arange(n)
-    for t in range(2):
+    for t in range(ticks):
         crate.physics_tick()
         for b in orc.rigid_bodies:
             b.advance(orc.coef["dt"])

@@ -128,6 +128,12 @@ def test_config4_eight_slabs_at_16m_with_the_motored_wall(sc):
     assert_chain_equals_single(chain, single)
     start = sc.Crate(copy.deepcopy(wc), noise="none", capacity=16).segments
     assert not np.array_equal(segments, start)  # the wall did move
+    # ... and the size-independent properties of the sort and the lists at this very size (the chain's memory goes first)
+    del chain, single
+    import gc
+    gc.collect()
+    mean_neighbors = lean_properties(sc, wc, p, v, d)
+    assert 11.0 < mean_neighbors < 13.5
 
 
 def test_message_sizes_follow_the_halo_counts(sc):
@@ -302,4 +308,31 @@ def test_row_slabs_equal_the_single_domain(sc, overlap, band_flag):
     chain = SlabChain(copy.deepcopy(wc), p, v, 3, noise="counter", noise_seed=1, overlap=False, axis="y")
     chain.run(ticks)
     chain.synchronize()
+    assert_chain_equals_single(chain, single)
+
+
+@pytest.mark.parametrize("axis", ["x", "y"])
+def test_wave_machine_scene_with_its_source_under_slabs(sc, axis):
+    """config/wave_machine.yaml unchanged -- it starts empty and its particle source emits for 500 ticks
+    (crate.py:138-147) -- on two slabs, through the source's whole active time and beyond: every slab draws the same new
+    particles and keeps the ones it owns; the result is the single-domain `Crate` (same host draws, counter noise) bit
+    for bit."""
+    from pathlib import Path
+    from sand_crate_amd.slab import SlabChain
+    ticks = 520
+    cfg = Path(__file__).resolve().parent.parent / "config" / "wave_machine.yaml"
+    crate = sc.Crate(sc.load_config(cfg).world_config, noise="counter", noise_seed=3)  # seeds np.random (crate.py:22)
+    for _ in range(ticks):
+        crate.physics_tick()
+    single = crate.engine.download()
+    crate.engine.close()
+    assert len(single[3]) > 2500
+    empty = np.zeros((0, 2))
+    chain = SlabChain(sc.load_config(cfg).world_config, empty, empty, 2, noise="counter", noise_seed=3, axis=axis)
+    chain.run(ticks)
+    chain.synchronize()
+    counts = chain.owned_counts()
+    assert sum(counts) == len(single[3])
+    if axis == "x":
+        assert min(counts) > 200  # the fluid did spread over both slabs
     assert_chain_equals_single(chain, single)

@@ -99,6 +99,50 @@ def test_rebalanced_slabs_equal_single_domain(tmp_path, nproc, n):
     assert np.array_equal(got["pressure"], pr)
 
 
+@pytest.mark.parametrize("axis", ["x", "y"])
+def test_scene_with_its_particle_source_under_slabs(tmp_path, axis):
+    """config/wave_machine.yaml as shipped -- empty at tick 0, its source emitting ~14 particles per tick (crate.py:138-147,
+    particle_source.py:17-24) -- on two slabs: every rank draws the same new particles from the same host stream and keeps
+    the ones it owns; the result is the single-domain run (same draws, counter noise) bit for bit.  With slabs of
+    columns the jet crosses the cut at x = 0.5 around tick 75."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import sand_crate_amd as sc
+    from oracle.tick import BodyState, counter_noise_key, counter_noise_u01, remove_outside, tick_core
+    from oracle.world import build_bodies
+    from sand_crate_amd.particle_source import build_particle_sources
+    from sand_crate_amd.slab import draw_new_particles
+    ticks = 110
+    got = run_workers(2, tmp_path / "slab.npz", "--backend", "oracle", "--scene", "wave_machine.yaml", "--ticks", str(ticks),
+                      "--noise", "counter", "--axis", axis)
+    wc = sc.load_config(ROOT / "config" / "wave_machine.yaml").world_config
+    co = dict(wc.coefficients)
+    co["gravity"] = np.array(co["gravity"], dtype=np.float64)
+    bodies = build_bodies(wc.rigid_bodies)
+    sources = build_particle_sources(wc.particle_sources)
+    np.random.seed(0)
+    p, v, ids, next_id = np.zeros((0, 2)), np.zeros((0, 2)), np.zeros(0, dtype=np.int64), 0
+    for t in range(ticks):
+        for new_p, new_v in draw_new_particles(sources, t, co["dt"], int(co["max_particles"]), len(p)):
+            p, v = np.vstack((p, new_p)), np.vstack((v, new_v))
+            ids = np.concatenate((ids, next_id + np.arange(len(new_p))))
+            next_id += len(new_p)
+        p, v, ids = remove_outside(p, v, co["particle_radius"], ids)
+        for b in bodies:
+            b.advance(co["dt"])
+        seg = np.vstack([b.segments for b in bodies])
+        bs = [BodyState(np.asarray(b.position, float), np.asarray(b.center_velocity, float),
+                        float(b.angular_clockwise_velocity), len(b)) for b in bodies]
+        out = tick_core(p, v, seg, bs, co, eta_u01=counter_noise_u01(ids, counter_noise_key(9, t)))
+        p, v, pr = out["particles"], out["velocities"], out["pressure"]
+    assert len(ids) > 500 and int(got["count"]) == len(ids)
+    if axis == "x":
+        assert (p[:, 0] > 0.55).sum() > 20  # the jet did cross the cut
+    assert np.array_equal(got["ids"], ids)
+    assert np.array_equal(got["particles"], p)
+    assert np.array_equal(got["velocities"], v)
+    assert np.array_equal(got["pressure"], pr)
+
+
 def test_rebalanced_cuts_properties():
     from sand_crate_amd.slab import HALO_COLUMNS, partition_columns, rebalanced_cuts
     rs = np.random.RandomState(1)
