@@ -272,6 +272,10 @@ def main() -> None:
 
     slab_sim = []
     band_mode = {}
+    # The contract workload piles up along floor and ceiling -- with slabs of rows into the first and the last slab --, so a
+    # window longer than the driver's (5 + 20 ticks: still uniform) re-derives the cuts from the global histogram now and
+    # then (one small all-reduce; SlabCrate.rebalance_every).  In the driver's window the cuts stay where they are.
+    rebalance_every = 50 if world > 1 and args.warmup + args.steps > 100 else 0
 
     def pick_band_mode(sim):
         """Halo overlap with slabs of rows: the force kernel either runs as two launches with an event in between or as
@@ -328,7 +332,8 @@ def main() -> None:
             if slab_sim:
                 slab_sim[0].reload(p, v)
             else:
-                slab_sim.append(SlabCrate(w, p, v, device=local_rank, noise=args.noise, noise_seed=1, axis=args.slab_axis))
+                slab_sim.append(SlabCrate(w, p, v, device=local_rank, noise=args.noise, noise_seed=1, axis=args.slab_axis,
+                                          rebalance_every=rebalance_every))
                 pick_band_mode(slab_sim[0])
             return slab_sim[0]
         s = sc.Crate(w, device=local_rank, noise=args.noise, noise_seed=1, capacity=n_total + 1024)
@@ -418,15 +423,28 @@ def main() -> None:
         settle(sim)
         eng.reset_timing()
         eng.enable_timing(True)
+        if world > 1:
+            sim.time_exchanges(True)
         sim.run(args.steps)
         settle(sim)
         eng.enable_timing(False)
         timing = eng.timing()
     heater = None
+    halo_by_rank = None
+    if world > 1:  # what every rank's halo exchange moved (and, from the replay above, took)
+        import torch.distributed as dist
+        halo_by_rank = [None] * world
+        dist.all_gather_object(halo_by_rank, slab_sim[0].exchange_stats())
+        slab_sim[0].time_exchanges(False)
 
+    if world == 1:
+        scaling = "weak"
+    else:  # BASELINE.json's configurations: 1,048,576 per GPU at 1, 2 and 4 GPUs, 2,097,152 per GPU (configs[4]) at 8
+        scaling = "weak" if per_gpu == TOTAL_BY_GPUS[1] else (f"weak, with {per_gpu / TOTAL_BY_GPUS[1]:g}x the per-GPU work of N=1 "
+                                                             f"({per_gpu} particles per GPU: BASELINE.json's configuration for {world} GPUs)")
     base = {"metric": "particle-steps/sec", "value": n_total * args.steps / elapsed, "unit": "particle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "repeats": {"count": len(reps), "ms_per_step": [round(1000.0 * r / args.steps, 5) for r in reps],
                         "min": round(1000.0 * order[0] / args.steps, 5), "max": round(1000.0 * order[-1] / args.steps, 5),
                         "value_is": "median repetition",
@@ -437,7 +455,8 @@ def main() -> None:
                        "particles_per_gpu": per_gpu, "particles_total": n_total, "live_after_run": int(n_live),
                        "parallelism": "single GPU" if world == 1 else f"{world} slabs of {'rows' if args.slab_axis == 'y' else 'columns'}, halo exchange per tick",
                        "transport": transport, "halo_overlap": bool(slab_sim[0].overlap) if world > 1 else None,
-                       "halo_overlap_band_mode_ms_per_tick": band_mode or None}}
+                       "halo_overlap_band_mode_ms_per_tick": band_mode or None,
+                       "rebalance_every": rebalance_every if world > 1 else None, "halo_by_rank": halo_by_rank}}
     if rank == 0 and args.no_kernel_events:
         base["note"] = "no per-kernel events"
         print(json.dumps(base))

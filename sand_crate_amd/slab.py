@@ -433,6 +433,19 @@ class SlabCrate:
             be.recv_left.fill_(-1.0)
             be.recv_right.fill_(-1.0)
             be.exchange_rccl(self.left, self.right)
+            # A send / receive pair that never completes would otherwise hold this rank until the launcher's limit with
+            # nothing on the screen.  Nothing can be enqueued behind a wedged exchange either, so there is no falling
+            # back from here: the wait is bounded and says what to do (SANDCRATE_TRANSPORT=torch skips this path).
+            limit = float(os.environ.get("SANDCRATE_RCCL_PROOF_TIMEOUT", "120"))
+            stream = be.side_stream() if self.overlap and be.side_stream() is not None else torch.cuda.current_stream(dev)
+            import time
+            t0 = time.monotonic()
+            while not stream.query():
+                if time.monotonic() - t0 > limit:
+                    raise TimeoutError(f"rank {self.rank}: the RCCL proof exchange with ranks {self.left} / {self.right} did not "
+                                       f"complete within {limit:.0f} s; run with SANDCRATE_TRANSPORT=torch to use the "
+                                       f"torch.distributed transport instead")
+                time.sleep(0.002)
             be.engine.synchronize()
             torch.cuda.synchronize(dev)
             if self.left is not None:
@@ -447,10 +460,42 @@ class SlabCrate:
         if all_ok(ok):
             self.transport = "rccl"
 
+    def time_exchanges(self, on: bool = True) -> None:
+        """Bracket every halo exchange with two events on the stream it is enqueued on (`exchange_stats`); off by default."""
+        self._xchg_events = [] if on and hasattr(self.backend, "torch") else None
+
+    def exchange_stats(self) -> dict:
+        """What this rank's halo exchanges moved and took: records per message of the last exchange (as sent: the count
+        six ticks earlier + 50 % + 1024, in steps of 256 -- sc_halo_sizes), and, after `time_exchanges()` and a
+        `synchronize()`, the mean time from an exchange's enqueueing on its stream to its completion there (with halo
+        overlap that includes the side stream's wait for the band blocks of the force kernel)."""
+        out = {"rank": self.rank, "transport": self.transport, "overlap": bool(self.overlap), "rebalances": self.rebalances}
+        if self._sizes is not None:
+            sl, rl, sr, rr = self._sizes
+            out.update(records_to_left=int(sl) if self.left is not None else 0, records_from_left=int(rl) if self.left is not None else 0,
+                       records_to_right=int(sr) if self.right is not None else 0, records_from_right=int(rr) if self.right is not None else 0)
+        ev = getattr(self, "_xchg_events", None)
+        if ev:
+            out["exchange_us_mean"] = round(1000.0 * sum(a.elapsed_time(b) for a, b in ev) / len(ev), 2)
+            out["exchanges_timed"] = len(ev)
+        return out
+
     def _exchange(self) -> None:
         """One message each way with each existing neighbor, of the sizes agreed for this tick."""
         if self.world == 1 or self._chained:
             return
+        ev = getattr(self, "_xchg_events", None)
+        if ev is None:
+            return self._exchange_now()
+        torch = self.backend.torch
+        stream = self.backend.side_stream() if self.overlap else torch.cuda.current_stream(self.backend.device)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)  # (with halo overlap the side stream then waits for the force kernel's band blocks: that wait is inside)
+        self._exchange_now()
+        b.record(stream)
+        ev.append((a, b))
+
+    def _exchange_now(self) -> None:
         dist, be = self.dist, self.backend
         sl, rl, sr, rr = self._sizes
         if self.transport == "rccl":

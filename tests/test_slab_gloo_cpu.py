@@ -143,6 +143,32 @@ def test_scene_with_its_particle_source_under_slabs(tmp_path, axis):
     assert np.array_equal(got["pressure"], pr)
 
 
+@pytest.mark.parametrize("nproc,per_gpu,extra", [(2, 1500, ()), (8, 3000, ("--steps", "103"))])
+def test_bench_multi_gpu_path_on_cpu(nproc, per_gpu, extra):
+    """bench.py's own N > 1 driver code (the path the driver's 2-, 4- and 8-GPU runs take: slabs of rows, halo overlap
+    requested, torch.distributed transport as the fallback, repetitions through `reload`, the JSON line) with the compute
+    side swapped for the oracle backend, under gloo: 2 ranks, and the 8-rank chain -- once with a window long enough for
+    the re-balancing of the cuts to switch on."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(ROOT / "tests" / "bench_worker.py"),
+           "--gpus", str(nproc), "--rehearse-on-one-gpu", "--particles", str(per_gpu), "--steps", "3", "--warmup", "1",
+           "--repeats", "2", "--clock-warmup", "0", "--cpu-sample", "0", "--no-kernel-events", *extra]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == nproc and line["metric"] == "particle-steps/sec" and line["value"] > 0
+    assert line["config"]["particles_total"] == nproc * per_gpu and line["config"]["live_after_run"] > 0.9 * nproc * per_gpu
+    assert line["config"]["parallelism"].startswith(f"{nproc} slabs of rows")
+    assert line["scaling"].startswith("weak")
+    halo = line["config"]["halo_by_rank"]
+    assert [h["rank"] for h in halo] == list(range(nproc))
+    assert halo[0]["records_to_left"] == 0 and halo[0]["records_to_right"] > 0 and halo[-1]["records_to_right"] == 0
+    assert line["config"]["rebalance_every"] == (50 if "--steps" in extra else 0)
+    if "--steps" in extra:
+        assert max(h["rebalances"] for h in halo) >= 1
+
+
 def test_rebalanced_cuts_properties():
     from sand_crate_amd.slab import HALO_COLUMNS, partition_columns, rebalanced_cuts
     rs = np.random.RandomState(1)
