@@ -440,8 +440,9 @@ def main() -> None:
     if world == 1:
         scaling = "weak"
     else:  # BASELINE.json's configurations: 1,048,576 per GPU at 1, 2 and 4 GPUs, 2,097,152 per GPU (configs[4]) at 8
+        why = f"BASELINE.json's configuration for {world} GPUs" if args.particles <= 0 else "--particles"
         scaling = "weak" if per_gpu == TOTAL_BY_GPUS[1] else (f"weak, with {per_gpu / TOTAL_BY_GPUS[1]:g}x the per-GPU work of N=1 "
-                                                             f"({per_gpu} particles per GPU: BASELINE.json's configuration for {world} GPUs)")
+                                                             f"({per_gpu} particles per GPU: {why})")
     base = {"metric": "particle-steps/sec", "value": n_total * args.steps / elapsed, "unit": "particle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",

@@ -233,30 +233,45 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
             probe.clock_stage();
             const int ws = rws;
             auto inside = [&](int p) { return (unsigned)(p - ws) < (unsigned)CAP; };
-            // kWinBatch candidates per iteration, their LDS reads issued together (a dependent read per candidate made
-            // this loop a chain of LDS latencies: in a pile 32 of them per thread and scan) and their verdicts formed
-            // side by side; what the scan does with them is then decided in order, as predicates instead of branches (a
-            // lone wave issues an instruction every 5-9 clocks: the branchy form spent a thousand clocks per batch)
-            constexpr int kWinBatch = 4;
-            for (int b = 0; b < kSerial && left > 0 && inside(pos); b += kWinBatch) {
+            // This thread's next stretch inside the window, at most kSerial candidates, walked like an LDS tile's scan:
+            // kWinBatch candidates per iteration, their LDS reads issued together, hits decided exactly, an append is a
+            // store and a clamped add (no branch), the batch's last candidate decides a conservative stop.  For that
+            // last candidate to be one of the scan's own the stretch is a multiple of kWinBatch unless the range ends
+            // in it (up to three candidates before the window's end wait for the wave-wide turn or the next window).
+            constexpr int kWinBatch = SC_SCAN_BATCH;
+            static_assert(kSerial % kWinBatch == 0, "the serial stretch is a whole number of batches");
+            {
               const int avail = step > 0 ? ws + CAP - pos : pos - ws + 1;  // slots of the window from pos on
-              const int nv = min(min(left, avail), kWinBatch);             // candidates of this batch
-              XY q[kWinBatch];
+              const int lim = left <= avail ? left : (avail & ~(kWinBatch - 1));
+              const int cnt = left > 0 && inside(pos) ? min(lim, kSerial) : 0;
+              const int base = pos - ws;
+              unsigned lw = lo0 + (unsigned)C * kRow;
+              bool stopped = false;
+              int v = 0;
+              for (; v < cnt && !stopped; v += kWinBatch) {
+                XY q[kWinBatch];
 #pragma unroll
-              for (int k = 0; k < kWinBatch; ++k) q[k] = txy[k < nv ? pos + k * step - ws : 0];
-              bool over = false;
+                for (int k = 0; k < kWinBatch; ++k) q[k] = txy[base + (v + k) * step];
+                unsigned inc[kWinBatch];
 #pragma unroll
-              for (int k = 0; k < kWinBatch; ++k) {
-                const int verdict = window(q[k].x, xi);
-                const double dx = q[k].x - xi, dy = q[k].y - yi;
-                const bool act = k < nv && !over;  // the scan gets as far as this candidate
-                const bool hit = act && verdict == 2 && dx * dx + dy * dy <= w.t_nbr;
-                if (hit) list[C][t] = (unsigned short)(pos + k * step);
-                C += hit ? 1 : 0;
-                over = over || (act && (verdict == 0 || C == kMaxNbr));
+                for (int k = 0; k < kWinBatch; ++k) {
+                  const double dx = q[k].x - xi, dy = q[k].y - yi;
+                  const bool hit = (dx * dx + dy * dy <= w.t_nbr) & (window(q[k].x, xi) == 2) & (v + k < cnt);
+                  inc[k] = hit ? kRow : 0u;
+                }
+                const double dxl = q[kWinBatch - 1].x - xi;
+                const bool stop = step > 0 ? dxl > dstop : dxl < -dstop;
+#pragma unroll
+                for (int k = 0; k < kWinBatch; ++k) {  // trim (:91-93): a full list writes its spare row
+                  *(unsigned short*)(lbase + lw) = (unsigned short)(pos + (v + k) * step);
+                  lw = min(lw + inc[k], lend);
+                }
+                stopped = stop | (lw == lend);
               }
-              pos += nv * step;
-              left = over ? 0 : left - nv;
+              const int walked = min(v, cnt);
+              C = (int)((lw - lo0) / kRow);
+              pos += walked * step;
+              left = stopped ? 0 : left - walked;
             }
             probe.clock_serial();
             unsigned long long m = __ballot(left > 0 && inside(pos));
@@ -802,6 +817,7 @@ __device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl,
 // crate.py:110-123 and averages |dv| of each) -- `mon` receives this particle's |dv| per phase, in the order
 // tension, gravity, pressure, viscosity, wall_bounce, continuous_collision.
 constexpr int kMonPhases = 6;
+constexpr double kNearSteps = 8.0;  // cells a particle may move per tick and still be served by its block's near-segment masks
 template <bool LDS, bool MON>
 __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, const XY* tv, const int C, const int Cn,
                                               const int ws, const int (&js)[kMaxNbr], const double* __restrict__ vx,
@@ -879,9 +895,10 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
     const double bx = xi + mx, by = yi + my;    // crate.py:183-184
     const double abx = bx - xi, aby = by - yi;  // geometry_utils.py:205 uses (b - a)
     double fac = 1.0;
-    // (the lanes that are here move less than 2 d -- then only the segments near the block can be crossed -- or the
-    // wave looks at every segment)
-    const unsigned segs = __ballot(!(mx * mx + my * my < w.ccd_skip2)) ? ~0u : near_now;
+    // (the lanes that are here move less than kNearSteps d -- then only the segments near the block can be crossed --
+    // or the wave looks at every segment)
+    const double reach = kNearSteps * w.d * (1 - 1e-6);
+    const unsigned segs = __ballot(!(mx * mx + my * my < reach * reach)) ? ~0u : near_now;
     for (int mm = 0; mm < 2 * w.nseg; ++mm) {
       if (!(segs >> (mm < w.nseg ? mm : mm - w.nseg) & 1u)) continue;  // the padded twins of segment k: k and nseg + k
       const Seg s = w.pad[mm];
@@ -920,8 +937,8 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
 // kept out of the default kernel, where its branches cost 0.8 us per tick in scalar registers
 // (diagnostic build: the stamps of even and odd ticks go to different buffers, so that the last tick of a run -- which has
 // no look-ahead -- does not overwrite the tick before it)
-#define SC_STAMP_B(slot) SC_STAMP((w.tick & 1) ? 2 : 1, slot)
-#define SC_STAMP_VALUE_B(slot, value) SC_STAMP_VALUE((w.tick & 1) ? 2 : 1, slot, value)
+#define SC_STAMP_B(slot) SC_STAMP((w.tick & 1) ? 3 : 1, slot)
+#define SC_STAMP_VALUE_B(slot, value) SC_STAMP_VALUE((w.tick & 1) ? 3 : 1, slot, value)
 template <int NOISE, bool FUSED, bool MON = false, bool GROUP = false, bool BANDED = false>
 __global__ void __launch_bounds__(kTileW)
     k_pass_b(World w, int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
@@ -1026,11 +1043,13 @@ __global__ void __launch_bounds__(kTileW)
   // start-of-tick positions lie in the box spanned by its first and last particle (one strip: between their x; more:
   // the full width; in y within a cell height of their y), and lane k holds segment k's distance to that box -- one pass
   // for all segments instead of a loop over them per particle.  Two masks, a bit per segment, the same in every lane:
-  //   near_now   this tick's segments within far_box of the box: the only ones a particle that moves less than 2 d can
-  //              cross (pass_b_finish; far_box = r + 2 d is what `wslot == -1` already stands for, per particle);
-  //   near_next  the next tick's segments within far_box + kMove of the box: the only ones the look-ahead wall pass has to
-  //              look at for a particle that moved less than kMove = 2 d (19 of 20 blocks have none: the loop over the
+  //   near_now   this tick's segments within r + kNearSteps d of the box: the only ones a particle that moves less than
+  //              kNearSteps d can cross (pass_b_finish);
+  //   near_next  the next tick's segments within far_box + kNearSteps d of the box: the only ones the look-ahead wall pass
+  //              has to look at for a particle that moved less than that (19 of 20 blocks have none: the loop over the
   //              segments was most of the 2.4 us that epilogue added to a wave's 8.4).
+  // kNearSteps = 8 cells: the contract workload heats up until its fastest particles cross several cells per tick; a
+  // wave with one such particle used to fall back to every segment.
   // The loads are requested here; the masks are formed behind the tile's loads, before the barrier.
   const int ilast = i0 + m - 1;
   const int cell_first = cell[i0], cell_last = cell[ilast];
@@ -1090,7 +1109,7 @@ __global__ void __launch_bounds__(kTileW)
     }
   }
   unsigned near_now, near_next = ~0u;
-  const double kMove = 2 * w.d;
+  const double kMove = kNearSteps * w.d;
   {
     // one strip: the last particle's cell is less than a row of cells after the first one's and its x is not smaller
     // (in a later strip either the cell is a row further or the column -- hence x -- is smaller)
@@ -1103,7 +1122,9 @@ __global__ void __launch_bounds__(kTileW)
     };
     double ox, oy;
     box_gap(seg_now, ox, oy);
-    near_now = (unsigned)__ballot((t & 63) < w.nseg && ox <= w.far_box && oy <= w.far_box);
+    // (far_box = r + 2 d, what a step of 2 d can reach: kNearSteps - 2 more cells for the steps the crossing test allows)
+    const double reach_now = w.far_box + (kNearSteps - 2) * w.d;
+    near_now = (unsigned)__ballot((t & 63) < w.nseg && ox <= reach_now && oy <= reach_now);
     if (FUSED) {
       box_gap(seg_next, ox, oy);
       near_next = (unsigned)__ballot((t & 63) < wn.nseg && ox <= wn.far_box + kMove && oy <= wn.far_box + kMove);

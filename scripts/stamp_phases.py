@@ -13,7 +13,7 @@ p, v = bench.synthetic_state(n)
 s.particles = p; s.particle_velocities = v
 s.run(20); s.synchronize()
 lib = N.load()
-buf = np.zeros((3, 1 << 16, 24), dtype=np.int64)
+buf = np.zeros((4, 1 << 16, 24), dtype=np.int64)
 lib.sc_debug_stamps.restype = C.c_int
 lib.sc_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
 assert lib.sc_debug_stamps(s.engine._ctx, buf.ctypes.data_as(C.c_void_p)) == 0
@@ -23,7 +23,7 @@ names = {0: ["start", "cell+buckets loaded", "tile staged", "scan same-row right
          1: ["start", "bounds, lane, table loaded", "tile staged", "pair loop", "velocities staged", "viscosity+finish",
              "next tick's wall pass", "stores"]}
 for k, label in ((0, "pass A"), (1, "pass B")):
-    st = buf[k if k == 0 else (1 if (buf[1, :waves, 7] > buf[2, :waves, 7]).mean() > 0.5 else 2), :waves, :len(names[k])]
+    st = buf[k if k == 0 else (1 if (buf[1, :waves, 7] > buf[3, :waves, 7]).mean() > 0.5 else 3), :waves, :len(names[k])]
     ok = (st > 0).all(axis=1)
     st = st[ok]
     dt = np.diff(st, axis=1)

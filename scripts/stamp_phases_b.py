@@ -13,7 +13,7 @@ p, v = bench.synthetic_state(n)
 s.particles = p; s.particle_velocities = v
 s.run(20); s.synchronize()
 lib = N.load()
-buf = np.zeros((3, 1 << 16, 24), dtype=np.int64)
+buf = np.zeros((4, 1 << 16, 24), dtype=np.int64)
 lib.sc_debug_stamps.restype = C.c_int
 lib.sc_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
 assert lib.sc_debug_stamps(s.engine._ctx, buf.ctypes.data_as(C.c_void_p)) == 0
@@ -21,7 +21,7 @@ waves = (n + 63) // 64
 order = [0, 1, 2, 3, 4, 5, 16, 17, 18, 19, 6, 7]
 names = ["bounds, lane, table loaded", "tile staged", "pair loop", "velocities staged", "viscosity+finish",
          "look-ahead: near segments", "look-ahead: wall_and_cell", "look-ahead: cell stores", "look-ahead: count_cells", "halo pack", "stores"]
-for k in (1, 2):
+for k in (1, 3):
     st = buf[k, :waves]
     fused = (st[:, 16] > 0).mean() > 0.5
     cols = order if fused else [0, 1, 2, 3, 4, 5, 6, 7]
