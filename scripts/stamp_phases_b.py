@@ -11,7 +11,8 @@ wc, d = bench.world_for(n)
 s = sc.Crate(copy.deepcopy(wc), noise="counter", noise_seed=1, capacity=n + 1024)
 p, v = bench.synthetic_state(n)
 s.particles = p; s.particle_velocities = v
-s.run(20); s.synchronize()
+ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+s.run(ticks); s.synchronize()
 lib = N.load()
 buf = np.zeros((4, 1 << 16, 24), dtype=np.int64)
 lib.sc_debug_stamps.restype = C.c_int
