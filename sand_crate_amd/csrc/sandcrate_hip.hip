@@ -129,7 +129,8 @@ struct sc_ctx {
   int* nbr = nullptr;              // neighbor table of tiles beyond 65535 entries: -(sorted index + 1), 32 bit
   unsigned short* nbr16 = nullptr;  // neighbor table, slot-major: tile slots, 16 bit
   unsigned char* cnt = nullptr;
-  double *P = nullptr, *sx = nullptr, *sy = nullptr;
+  double* P = nullptr;
+  XY *sxy = nullptr, *svv = nullptr, *snn = nullptr;  // the sorted positions and velocities, the surface normals: 16-byte pairs
   int* counters = nullptr;
   // SC_NOISE_HOST
   int *cntById = nullptr, *offById = nullptr, *idBlockSums = nullptr;
@@ -473,8 +474,8 @@ template <int NOISE, bool ENUM, bool DENS, int CAP>
 void launch_pass_a_cap(sc_ctx* c) {
   auto launch = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters,
-                       c->x[1], c->y[1], c->id[1], c->cellT, Buckets{c->cellStart, c->blockOff}, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta, c->offById,
-                       c->P, c->sx, c->sy, ENUM ? c->tileBounds : c->tileBoundsT, c->tileBand, c->tileBoundsT);
+                       c->sxy, c->id[1], c->cellT, Buckets{c->cellStart, c->blockOff}, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta, c->offById,
+                       c->P, c->snn, ENUM ? c->tileBounds : c->tileBoundsT, c->tileBand, c->tileBoundsT);
   };
   if (ENUM && DENS && piles_expected(c))  // dense tiles ahead: the instantiation that stages their lists' reach
     launch(k_pass_a<NOISE, ENUM, DENS, CAP, ENUM && DENS>);
@@ -517,9 +518,9 @@ void launch_pass_b(sc_ctx* c, const WallInputs& wn, int part = 0) {
   const int grid = part == 1 && bandw ? 2 * bandw : part == 3 ? tile_grid(c) + 2 * bandw : tile_grid(c);
   hipStream_t stream = c->stream;
   auto launch = [&](auto kernel) {
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kTileW), 0, stream, c->w, c->counters, c->x[1], c->y[1], c->vx[1],
-                       c->vy[1], c->id[1], c->wslotT, c->cellT, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta, c->offById, c->P,
-                       c->sx, c->sy, c->wrec[cur], c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], c->tileBoundsT,
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kTileW), 0, stream, c->w, c->counters, c->sxy, c->svv,
+                       c->id[1], c->wslotT, c->cellT, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta, c->offById, c->P,
+                       c->snn, c->wrec[cur], c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], c->tileBoundsT,
                        c->bigHintDev, wn, c->cellS, c->wslotS, c->cellCount, c->wrec[nxt], c->haloL, c->haloR, c->haloCap,
                        c->monitor, c->tileBand, part, bandw, c->band_epoch);
   };
@@ -589,13 +590,13 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
   size_t n = (size_t)capacity;
   hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
   c->stream = c->own_stream;
-  for (int s = 0; s < 2 && e == hipSuccess; ++s) {
-    if (e == hipSuccess) e = dalloc(&c->x[s], n);
-    if (e == hipSuccess) e = dalloc(&c->y[s], n);
-    if (e == hipSuccess) e = dalloc(&c->vx[s], n);
-    if (e == hipSuccess) e = dalloc(&c->vy[s], n);
-    if (e == hipSuccess) e = dalloc(&c->id[s], n);
-  }
+  // [0]: the storage set (a tick's input and output); [1]: the sorted set, of which only the ids are an array of their
+  // own -- positions and velocities are the pairs sxy / svv
+  if (e == hipSuccess) e = dalloc(&c->x[0], n);
+  if (e == hipSuccess) e = dalloc(&c->y[0], n);
+  if (e == hipSuccess) e = dalloc(&c->vx[0], n);
+  if (e == hipSuccess) e = dalloc(&c->vy[0], n);
+  for (int s = 0; s < 2 && e == hipSuccess; ++s) e = dalloc(&c->id[s], n);
   if (e == hipSuccess) e = dalloc(&c->cellS, n);
   if (e == hipSuccess) e = dalloc(&c->wslotS, n);
   if (e == hipSuccess) e = dalloc(&c->cellT, n);
@@ -621,8 +622,9 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
   if (e == hipSuccess) e = dalloc(&c->nbr16, (size_t)kMaxNbr * n);
   if (e == hipSuccess) e = dalloc(&c->cnt, n);
   if (e == hipSuccess) e = dalloc(&c->P, n);
-  if (e == hipSuccess) e = dalloc(&c->sx, n);
-  if (e == hipSuccess) e = dalloc(&c->sy, n);
+  if (e == hipSuccess) e = dalloc(&c->snn, n);
+  if (e == hipSuccess) e = dalloc(&c->sxy, n);
+  if (e == hipSuccess) e = dalloc(&c->svv, n);
   if (e == hipSuccess) e = dalloc(&c->counters, (size_t)C_ALLOC);
   if (e == hipSuccess) e = hipMemsetAsync(c->counters, 0, C_ALLOC * sizeof(int), c->stream);
   if (e != hipSuccess) {
@@ -649,7 +651,7 @@ int sc_destroy(sc_ctx* c) {
   if (c->ev_band) (void)hipEventDestroy(c->ev_band);
   if (c->ev_xchg) (void)hipEventDestroy(c->ev_xchg);
   void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->keyCell, c->tileBounds, c->tileBoundsT, c->tileBand, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->bigTable, c->wrec[0], c->wrec[1],
-                  c->nbr, c->nbr16, c->cnt, c->P, c->sx, c->sy, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
+                  c->nbr, c->nbr16, c->cnt, c->P, c->snn, c->sxy, c->svv, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
                   c->stage_xy, c->stage_vxy, c->stage_ids, c->owned_out, c->colHist, c->rng, c->monitor,
                   c->snap_d[0], c->snap_d[1], c->snap_d[2], c->snap_d[3], c->snap_id_d, c->snap_rng_d};
   for (void* p : ptrs)
@@ -825,8 +827,8 @@ int sc_step_begin(sc_ctx* c) {
     Bracket br(c, K_REORDER);
     hipLaunchKernelGGL(k_reorder, dim3((int)std::max<int64_t>(1, (launch_bound(c) + kReorderBlock - 1) / kReorderBlock)),
                        dim3(kReorderBlock), 0, c->stream, c->counters, c->perm, c->keyX, c->keyId, c->keyCell,
-                       c->cellS, Buckets{c->cellStart, c->blockOff}, c->wslotS, c->y[0], c->vx[0], c->vy[0], c->x[1], c->y[1], c->vx[1],
-                       c->vy[1], c->id[1], c->cellT, c->wslotT, c->sortedStamp, stamp, w.ncols, c->tileBounds, w.live_hint);
+                       c->cellS, Buckets{c->cellStart, c->blockOff}, c->wslotS, c->y[0], c->vx[0], c->vy[0], c->sxy, c->svv,
+                       c->id[1], c->cellT, c->wslotT, c->sortedStamp, stamp, w.ncols, c->tileBounds, w.live_hint);
   }
   // SC_NOISE_HOST (and the stand-alone search) stop after the lists: the host's rand block can only be
   // indexed once every count is known.  Otherwise the search and pass A are one launch.
@@ -1107,14 +1109,14 @@ int sc_download_neighbors(sc_ctx* c, int64_t* ids, int32_t* counts, int64_t* nei
   if (n > room) return fail(SC_ERR_CAPACITY, "host arrays too small");
   std::vector<int> id(n);
   std::vector<unsigned char> cnt(n);
-  std::vector<double> hx(n), hy(n);
+  std::vector<double> hxy(2 * n);
   std::vector<int> slot(n);
   std::vector<unsigned short> slot16(n);
   const int64_t nblocks = (n + kTileW - 1) / kTileW;
   std::vector<int> tb(6 * std::max<int64_t>(nblocks, 1));
   if ((rc = fetch(c, tb.data(), c->tileBoundsT, 6 * nblocks * sizeof(int)))) return rc;
   if ((rc = fetch(c, id.data(), c->id[1], n * sizeof(int))) || (rc = fetch(c, cnt.data(), c->cnt, n)) ||
-      (rc = fetch(c, hx.data(), c->x[1], n * sizeof(double))) || (rc = fetch(c, hy.data(), c->y[1], n * sizeof(double))))
+      (rc = fetch(c, hxy.data(), c->sxy, 2 * n * sizeof(double))))
     return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
   if (neighbors)
@@ -1136,8 +1138,8 @@ int sc_download_neighbors(sc_ctx* c, int64_t* ids, int32_t* counts, int64_t* nei
     if (ids) ids[k] = id[k];
     if (counts) counts[k] = cnt[k];
     if (fixed_xy) {
-      fixed_xy[2 * k] = hx[k];
-      fixed_xy[2 * k + 1] = hy[k];
+      fixed_xy[2 * k] = hxy[2 * k];
+      fixed_xy[2 * k + 1] = hxy[2 * k + 1];
     }
   }
   return SC_OK;
@@ -1152,18 +1154,17 @@ int sc_download_normals(sc_ctx* c, double* sxy, int64_t room, int64_t* n_out) {
   int64_t n = h[C_NT];
   if (n_out) *n_out = n;
   if (n > room) return fail(SC_ERR_CAPACITY, "host arrays too small");
-  std::vector<double> a(n), b(n);
+  std::vector<double> ab(2 * n);
   std::vector<int> id(n);
-  if ((rc = fetch(c, a.data(), c->sx, n * sizeof(double))) || (rc = fetch(c, b.data(), c->sy, n * sizeof(double))) ||
-      (rc = fetch(c, id.data(), c->id[1], n * sizeof(int))))
+  if ((rc = fetch(c, ab.data(), c->snn, 2 * n * sizeof(double))) || (rc = fetch(c, id.data(), c->id[1], n * sizeof(int))))
     return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
   std::vector<int> order(n);
   std::iota(order.begin(), order.end(), 0);
   std::sort(order.begin(), order.end(), [&](int p, int q) { return id[p] < id[q]; });
   for (int64_t k = 0; k < n && sxy; ++k) {
-    sxy[2 * k] = a[order[k]];
-    sxy[2 * k + 1] = b[order[k]];
+    sxy[2 * k] = ab[2 * order[k]];
+    sxy[2 * k + 1] = ab[2 * order[k] + 1];
   }
   return SC_OK;
 }

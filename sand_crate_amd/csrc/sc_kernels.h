@@ -731,8 +731,8 @@ __global__ void __launch_bounds__(kReorderBlock)
     k_reorder(const int* __restrict__ counters, const int* __restrict__ perm, const double* __restrict__ keyX,
               const int* __restrict__ keyId, const int* __restrict__ keyCell, const int* __restrict__ cellS, Buckets bk,
               const int* __restrict__ wslotS, const double* __restrict__ yS, const double* __restrict__ vxS,
-              const double* __restrict__ vyS, double* __restrict__ xT, double* __restrict__ yT,
-              double* __restrict__ vxT, double* __restrict__ vyT, int* __restrict__ idT, int* __restrict__ cellT,
+              const double* __restrict__ vyS, XY* __restrict__ xyT, XY* __restrict__ vvT, int* __restrict__ idT,
+              int* __restrict__ cellT,
               int* __restrict__ wslotT, const int* __restrict__ sortedStamp, int stamp, int ncols,
               int* __restrict__ tileBounds, int live_hint) {
   SC_TIMELINE_KERNEL(4);
@@ -879,10 +879,8 @@ __global__ void __launch_bounds__(kReorderBlock)
     tb[3] = bk(c + ncols + 2);
     tb[5] = bk(c - ncols + 2);
   }
-  xT[dst] = xi;
-  yT[dst] = yi;
-  vxT[dst] = vxi;
-  vyT[dst] = vyi;
+  xyT[dst] = XY{xi, yi};  // the sorted arrays hold pairs: one 16-byte store and, in the passes that stage them, one load
+  vvT[dst] = XY{vxi, vyi};
   idT[dst] = idi;
   cellT[dst] = cpacked;
   wslotT[dst] = wsi;

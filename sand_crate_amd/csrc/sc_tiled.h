@@ -77,8 +77,6 @@ __device__ __forceinline__ double rsqrt_nr(double s) {
   return fma(y * e, p, y);
 }
 
-// (x, y) as one 16-byte vector, so that a tile read is a single ds_read_b128 / global_load_dwordx4
-typedef double XY __attribute__((ext_vector_type(2)));
 
 // XCD-aware block -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
 // b + 8 share an L2), while a tile overlaps its neighbors in the sorted order (same rows) and the
@@ -113,19 +111,19 @@ template <int NOISE, bool ENUM, bool DENS, bool LDS, int CAP, bool STAGE = false
 __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, const int total, XY* txy,
                                             unsigned short (*list)[kTileW + 2], int* wkey, const int t, const int i,
                                             const bool live, const int idi, const int e0, const int b0, const int b1,
-                                            const int e1, const int bm, const int em, const double* __restrict__ x,
-                                            const double* __restrict__ y, int* __restrict__ nbr,
+                                            const int e1, const int bm, const int em, const XY* __restrict__ sxy,
+                                            int* __restrict__ nbr,
                                             unsigned short* __restrict__ nbr16,
                                             unsigned char* __restrict__ cnt, const int cap,
                                             const double* __restrict__ eta, const int* __restrict__ offById,
-                                            double* __restrict__ P, double* __restrict__ sx, double* __restrict__ sy,
+                                            double* __restrict__ P, XY* __restrict__ snn,
                                             const int tile_id, int* __restrict__ tileBoundsT) {
   auto load_xy = [&](int slot) -> XY {
     if constexpr (LDS) {
       return txy[slot];
     } else {
       const int j = tile_index(tl, slot);
-      return XY{x[j], y[j]};
+      return sxy[j];
     }
   };
   const bool slots_fit = total <= kSlotMax;
@@ -222,7 +220,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
                 const int slot = rws + t + k * kTileW;
                 if (slot < total && t + k * kTileW < CAP) {
                   const int j = tile_index(tl, slot);
-                  r[k] = XY{x[j], y[j]};
+                  r[k] = sxy[j];
                 }
               }
 #pragma unroll
@@ -367,30 +365,34 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       const double xhi = xi + w.d, xlo = xi - w.d;
       auto push = [&](int j) { nbr[(size_t)C++ * cap + i] = -j - 1; };
       for (int j = i + 1; j < e0 && C < kMaxNbr; ++j) {
-        const double xj = x[j];
+        const XY pj = sxy[j];
+        const double xj = pj.x;
         if (xj > xhi) break;
-        const double dx = xj - xi, dy = y[j] - yi;
+        const double dx = xj - xi, dy = pj.y - yi;
         if (dx * dx + dy * dy <= w.t_nbr) push(j);
       }
       for (int j = b1; j < e1 && C < kMaxNbr; ++j) {
-        const double xj = x[j];
+        const XY pj = sxy[j];
+        const double xj = pj.x;
         if (xj > xhi) break;
         if (xj >= xlo) {
-          const double dx = xj - xi, dy = y[j] - yi;
+          const double dx = xj - xi, dy = pj.y - yi;
           if (dx * dx + dy * dy <= w.t_nbr) push(j);
         }
       }
       for (int j = i - 1; j >= b0 && C < kMaxNbr; --j) {
-        const double xj = x[j];
+        const XY pj = sxy[j];
+        const double xj = pj.x;
         if (!(xi <= xj + w.d)) break;
-        const double dx = xj - xi, dy = y[j] - yi;
+        const double dx = xj - xi, dy = pj.y - yi;
         if (dx * dx + dy * dy <= w.t_nbr) push(j);
       }
       for (int j = em - 1; j >= bm && C < kMaxNbr; --j) {
-        const double xj = x[j];
+        const XY pj = sxy[j];
+        const double xj = pj.x;
         if (!(xi <= xj + w.d)) break;
         if (xi >= xj - w.d) {
-          const double dx = xj - xi, dy = y[j] - yi;
+          const double dx = xj - xi, dy = pj.y - yi;
           if (dx * dx + dy * dy <= w.t_nbr) push(j);
         }
       }
@@ -488,7 +490,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
           const Tile part{nb[0], nb[1] - nb[0], nb[2], nb[3] - nb[2], nb[4], nb[5] - nb[4]};
           for (int slot = t; slot < mt; slot += kTileW) {
             const int j = tile_index(part, slot);
-            txy[slot] = XY{x[j], y[j]};
+            txy[slot] = sxy[j];
           }
           __syncthreads();
         }
@@ -536,7 +538,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
             qq[k] = load_xy(sk < C ? (int)list[sk][t] : self);
           } else {
             const int j = sk < C ? -nbr[(size_t)sk * cap + i] - 1 : i;
-            qq[k] = XY{x[j], y[j]};
+            qq[k] = sxy[j];
           }
         }
       }
@@ -556,8 +558,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       ay += g * ry;
     }
     P[i] = C ? fmax(((double)C - sumc) - w.ignored, 0.0) : 0.0;  // crate.py:265-273
-    sx[i] = ax;
-    sy[i] = ay;
+    snn[i] = XY{ax, ay};
   }
 
   SC_STAMP(0, 7);
@@ -610,11 +611,11 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
 // uniform regime 13 spilled scalar registers and 1 us per tick.
 template <int NOISE, bool ENUM, bool DENS, int CAP, bool STAGE = false>
 __global__ void __launch_bounds__(kTileW)
-    k_pass_a(World w, const int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
+    k_pass_a(World w, const int* __restrict__ counters, const XY* __restrict__ sxy,
              const int* __restrict__ id, const int* __restrict__ cell, Buckets bk,
              int* __restrict__ nbr, unsigned short* __restrict__ nbr16, unsigned char* __restrict__ cnt, int cap,
-             const double* __restrict__ eta, const int* __restrict__ offById, double* __restrict__ P, double* __restrict__ sx,
-             double* __restrict__ sy, const int* __restrict__ tileBounds, int* __restrict__ tileBand,
+             const double* __restrict__ eta, const int* __restrict__ offById, double* __restrict__ P, XY* __restrict__ snn,
+             const int* __restrict__ tileBounds, int* __restrict__ tileBand,
              int* __restrict__ tileBoundsT) {
   constexpr int kPad = SC_SCAN_BATCH - 1;  // a batched scan may read this far past either end of the tile
   __shared__ XY txy_padded[CAP + 2 * kPad];
@@ -688,7 +689,7 @@ __global__ void __launch_bounds__(kTileW)
       const int s = t + k * kTileW;
       if (s < total) {
         const int j = tile_index(tl, s);
-        r[k] = XY{x[j], y[j]};
+        r[k] = sxy[j];
       }
     }
 #pragma unroll
@@ -702,8 +703,8 @@ __global__ void __launch_bounds__(kTileW)
   SC_STAMP(0, 2);
 
   if (in_lds)
-    pass_a_body<NOISE, ENUM, DENS, true, CAP>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, x, y, nbr, nbr16, cnt,
-                                         cap, eta, offById, P, sx, sy, tile_id, tileBoundsT);
+    pass_a_body<NOISE, ENUM, DENS, true, CAP>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, sxy, nbr, nbr16, cnt,
+                                         cap, eta, offById, P, snn, tile_id, tileBoundsT);
   else {
     // Beyond the LDS budget the threads take the block's particles in stride (thread t: particle (t mod 64) * waves +
     // t / 64).  Consecutive particles share their surroundings, and the expensive ones -- sparse particles beside a
@@ -725,8 +726,8 @@ __global__ void __launch_bounds__(kTileW)
       bm = bk(c - w.ncols - 1);
       em = bk(c - w.ncols + 2);
     }
-    pass_a_body<NOISE, ENUM, DENS, false, CAP, STAGE && ENUM && DENS>(w, tl, total, txy, list, wkey, t, ip, livep, idp, e0, b0, b1, e1, bm, em, x, y, nbr,
-                                          nbr16, cnt, cap, eta, offById, P, sx, sy, tile_id, tileBoundsT);
+    pass_a_body<NOISE, ENUM, DENS, false, CAP, STAGE && ENUM && DENS>(w, tl, total, txy, list, wkey, t, ip, livep, idp, e0, b0, b1, e1, bm, em, sxy, nbr,
+                                          nbr16, cnt, cap, eta, offById, P, snn, tile_id, tileBoundsT);
   }
 }
 
@@ -756,10 +757,10 @@ struct PairSums {
 template <int NOISE, bool LDS, bool MON>
 __device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl, const XY* txy, const XY* tss,
                                                  const double* tP, const int self, const int Cn, const int idi,
-                                                 const int (&js)[kMaxNbr], const double* __restrict__ x,
-                                                 const double* __restrict__ y, const double* __restrict__ eta,
+                                                 const int (&js)[kMaxNbr], const XY* __restrict__ sxy,
+                                                 const double* __restrict__ eta,
                                                  const int* __restrict__ offById, const double* __restrict__ P,
-                                                 const double* __restrict__ sx, const double* __restrict__ sy,
+                                                 const XY* __restrict__ snn,
                                                  double& xi, double& yi, double& Pi) {
   // No decision is taken in this block, so multiply-adds may fuse (the file is compiled with -ffp-contract=off).  The
   // velocities it produces do feed decisions later -- the sign test of the wall bounce and the orientation tests of the
@@ -773,8 +774,8 @@ __device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl,
       pr = tP[e];
     } else {
       const int j = entry_index(tl, e);
-      pos = XY{x[j], y[j]};
-      nrm = XY{sx[j], sy[j]};
+      pos = sxy[j];
+      nrm = snn[j];
       pr = P[j];
     }
   };
@@ -820,8 +821,8 @@ constexpr int kMonPhases = 6;
 constexpr double kNearSteps = 8.0;  // cells a particle may move per tick and still be served by its block's near-segment masks
 template <bool LDS, bool MON>
 __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, const XY* tv, const int C, const int Cn,
-                                              const int ws, const int (&js)[kMaxNbr], const double* __restrict__ vx,
-                                              const double* __restrict__ vy, const double* __restrict__ wrec,
+                                              const int ws, const int (&js)[kMaxNbr], const XY* __restrict__ svv,
+                                              const double* __restrict__ wrec,
                                               const PairSums ps, const double xi, const double yi, const double Pi,
                                               double vxi, double vyi, double& xn, double& yn, double& vxn, double& vyn,
                                               double (&mon)[kMonPhases], const unsigned near_now = ~0u) {
@@ -835,7 +836,7 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
         ov = tv[js[s]];
       } else {
         const int j = entry_index(tl, js[s]);
-        ov = XY{vx[j], vy[j]};
+        ov = svv[j];
       }
       ux += ov.x;  // crate.py:175: the neighbors' start-of-tick velocities
       uy += ov.y;
@@ -941,13 +942,13 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
 #define SC_STAMP_VALUE_B(slot, value) SC_STAMP_VALUE((w.tick & 1) ? 3 : 1, slot, value)
 template <int NOISE, bool FUSED, bool MON = false, bool GROUP = false, bool BANDED = false>
 __global__ void __launch_bounds__(kTileW)
-    k_pass_b(World w, int* __restrict__ counters, const double* __restrict__ x, const double* __restrict__ y,
-             const double* __restrict__ vx, const double* __restrict__ vy, const int* __restrict__ id,
+    k_pass_b(World w, int* __restrict__ counters, const XY* __restrict__ sxy, const XY* __restrict__ svv,
+             const int* __restrict__ id,
              const int* __restrict__ wslot, const int* __restrict__ cell, const int* __restrict__ nbr,
              const unsigned short* __restrict__ nbr16,
              const unsigned char* __restrict__ cnt, int cap, const double* __restrict__ eta,
-             const int* __restrict__ offById, const double* __restrict__ P, const double* __restrict__ sx,
-             const double* __restrict__ sy, const double* __restrict__ wrec, double* __restrict__ xo,
+             const int* __restrict__ offById, const double* __restrict__ P, const XY* __restrict__ snn,
+             const double* __restrict__ wrec, double* __restrict__ xo,
              double* __restrict__ yo, double* __restrict__ vxo, double* __restrict__ vyo, int* __restrict__ ido,
              const int* __restrict__ tileBounds, volatile int* __restrict__ progress,
              WallInputs wn, int* __restrict__ cellS, int* __restrict__ wslotS, int* __restrict__ cellCount,
@@ -1053,7 +1054,8 @@ __global__ void __launch_bounds__(kTileW)
   // The loads are requested here; the masks are formed behind the tile's loads, before the barrier.
   const int ilast = i0 + m - 1;
   const int cell_first = cell[i0], cell_last = cell[ilast];
-  const double x_first = x[i0], x_last = x[ilast], y_first = y[i0], y_last = y[ilast];
+  const XY p_first = sxy[i0], p_last = sxy[ilast];
+  const double x_first = p_first.x, x_last = p_last.x, y_first = p_first.y, y_last = p_last.y;
   const int seg_k = min(t & 63, kMaxSeg - 1);
   const Seg seg_now = w.seg[seg_k];
   Seg seg_next{0, 0, 0, 0};
@@ -1083,7 +1085,8 @@ __global__ void __launch_bounds__(kTileW)
   // velocities wait in registers for their turn in the (x, y) array.
   constexpr int kPer = (kTileCapB + kTileW - 1) / kTileW;
   XY rv[kPer];
-  const double vx0 = vx[ic], vy0 = vy[ic];
+  const XY v0 = svv[ic];
+  const double vx0 = v0.x, vy0 = v0.y;
   if (in_lds) {
     XY rp[kPer], rs[kPer];
     double rP[kPer];
@@ -1092,10 +1095,10 @@ __global__ void __launch_bounds__(kTileW)
       const int s = t + k * kTileW;
       if (s < total) {
         const int j = tile_index(tl, s);
-        rp[k] = XY{x[j], y[j]};
-        rs[k] = XY{sx[j], sy[j]};
+        rp[k] = sxy[j];
+        rs[k] = snn[j];
         rP[k] = P[j];
-        rv[k] = XY{vx[j], vy[j]};
+        rv[k] = svv[j];
       }
     }
 #pragma unroll
@@ -1142,7 +1145,7 @@ __global__ void __launch_bounds__(kTileW)
   double xi = 0, yi = 0, Pi = 0;  // the particle's start-of-tick position and its pressure
   if (in_lds) {
     PairSums ps{0, 0, 0, 0};
-    if (active) ps = pass_b_pairs<NOISE, true, MON>(w, tl, txy, tss, tP, self, Cn, idi, js, x, y, eta, offById, P, sx, sy, xi, yi, Pi);
+    if (active) ps = pass_b_pairs<NOISE, true, MON>(w, tl, txy, tss, tP, self, Cn, idi, js, sxy, eta, offById, P, snn, xi, yi, Pi);
     SC_STAMP_B(3);
     __syncthreads();  // everybody is done with (x, y): the array now takes the velocities
 #pragma unroll
@@ -1154,12 +1157,12 @@ __global__ void __launch_bounds__(kTileW)
     SC_STAMP_B(4);
     if (active) {
       idn = idi;
-      pass_b_finish<true, MON>(w, tl, txy, C, Cn, ws, js, vx, vy, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn, mon, near_now);
+      pass_b_finish<true, MON>(w, tl, txy, C, Cn, ws, js, svv, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn, mon, near_now);
     }
   } else if (active) {
     idn = idi;
-    const PairSums ps = pass_b_pairs<NOISE, false, MON>(w, tl, txy, tss, tP, self, Cn, idi, js, x, y, eta, offById, P, sx, sy, xi, yi, Pi);
-    pass_b_finish<false, MON>(w, tl, txy, C, Cn, ws, js, vx, vy, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn, mon, near_now);
+    const PairSums ps = pass_b_pairs<NOISE, false, MON>(w, tl, txy, tss, tP, self, Cn, idi, js, sxy, eta, offById, P, snn, xi, yi, Pi);
+    pass_b_finish<false, MON>(w, tl, txy, C, Cn, ws, js, svv, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn, mon, near_now);
   }
   SC_STAMP_B(5);
   if constexpr (MON) {  // sums over the wave, one atomic per wave and phase; [kMonPhases] counts the particles
