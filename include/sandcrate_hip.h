@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 3
+#define SC_ABI_VERSION 4
 #define SC_MAX_NEIGHBORS 20 /* collision_detector.py:6  MAX_ALLOWED_NEIGHBORS */
 #define SC_MAX_SEGMENTS 16  /* wall segments of all rigid bodies together (scenes use 6 and 8) */
 #define SC_MAX_BODIES 8
