@@ -17,6 +17,7 @@ MAX_BODIES = 8
 NUM_KERNELS = 12
 NOISE_NONE, NOISE_HOST, NOISE_COUNTER = 0, 1, 2
 ERR_CAPACITY = -3
+ERR_STATE = -4
 ERR_DOMAIN = -5
 
 

@@ -437,3 +437,86 @@ def test_bucket_sizes_around_every_ranking_path(sc):
     assert np.array_equal(order, ref_order)
     assert np.array_equal(rows, ref_rows)
     assert counts.max() <= 20 and len(table) == len(pts)  # the lists themselves: test_pile_up_buckets_sort_and_rank
+
+
+# ------------------------------------------------------------------ checkpoints: the corners ADVICE.md (round 2) named
+def test_checkpoint_of_a_slab_context_with_halo_overlap(sc):
+    """A slab context whose side stream already exists (halo overlap creates it) takes a checkpoint all the same -- the
+    snapshot's events and pinned buffers are created on their own -- and gives back what it holds."""
+    from test_gpu_parity import synthetic, wave_world
+    n = 30000
+    p, v, d = synthetic(n, seed=12)
+    eng = sc.Engine(n + 64)
+    from sand_crate_amd import _native as N
+    eng.set_noise_mode(N.NOISE_COUNTER, 5)
+    crate_like = sc.Crate(wave_world(sc, d, 0.1), noise="counter", capacity=16)  # only for the tick inputs
+    eng.set_slab(-2 ** 40, 2 ** 40, 3, False, False)   # one slab that owns everything
+    eng.set_halo_overlap(True)                         # -> the side stream exists before the first checkpoint
+    ids = np.arange(n, dtype=np.int64)[::-1].copy()    # any ids: they come back sorted
+    eng.upload_with_ids(p, v, ids)
+    eng.checkpoint_begin()
+    snap = eng.checkpoint_finish()
+    order = np.argsort(ids)
+    assert np.array_equal(snap["ids"], ids[order])
+    assert np.array_equal(snap["particles"], p[order]) and np.array_equal(snap["velocities"], v[order])
+    eng.close()
+    crate_like.engine.close()
+
+
+def test_checkpoint_is_refused_while_a_promised_tick_is_pending(sc):
+    """After sc_set_next_inputs promised the next tick the storage arrays hold that tick's wall pass already:
+    sc_checkpoint_begin says so instead of capturing a state that would run the wall pass twice."""
+    from sand_crate_amd import _native as N
+    from test_gpu_parity import synthetic, wave_world
+    n = 5000
+    p, v, d = synthetic(n, seed=13)
+    crate = sc.Crate(wave_world(sc, d, 0.1), noise="counter", noise_seed=1, capacity=n + 16)
+    crate.particles = p
+    crate.particle_velocities = v
+    eng = crate.engine
+    for b in crate.rigid_bodies:
+        b.apply_velocity(crate.dt)
+    now = crate._pack_tick_inputs()
+    for b in crate.rigid_bodies:
+        b.apply_velocity(crate.dt)
+    nxt = crate._pack_tick_inputs()
+    eng.tick(now, nxt)                                  # promises the tick after
+    with pytest.raises(N.NativeError) as err:
+        eng.checkpoint_begin()
+    assert err.value.code == N.ERR_STATE
+    eng.tick(nxt, None)                                 # the promised tick runs; nothing is pending any more
+    eng.checkpoint_begin()
+    assert len(eng.checkpoint_finish()["ids"]) == n
+
+
+def test_resume_after_the_fallback_to_the_host_stream(sc, tmp_path):
+    """A crate that started with the stream on the device and fell back to noise="host-sync" (a source outside the
+    inversion branch of the binomial) checkpoints the HOST stream -- the device's copy is stale by then -- and the
+    resumed run continues the uninterrupted one bit for bit."""
+    import warnings
+
+    def world():
+        wc = scene(sc, "wave_machine")
+        wc.particle_sources = [dict(radius=0.3, position=[0.05, 0.95], velocity=[3, 0.0], flow=20000, noise=0.0, active_ticks=500)]
+        return wc  # flow * dt = 40 > 30: BTPE
+
+    def run(crate, ticks):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            for _ in range(ticks):
+                crate.physics_tick()
+
+    a = sc.Crate(world(), noise="host")
+    with pytest.warns(RuntimeWarning, match="host-sync"):
+        a.physics_tick()
+    run(a, 23)
+    want = a.engine.download()
+    b = sc.Crate(world(), noise="host")
+    run(b, 12)
+    assert b._noise == "host-sync"
+    b.save_checkpoint(tmp_path / "ck.npz")
+    np.random.seed(7)
+    c = sc.Crate.from_checkpoint(tmp_path / "ck.npz")
+    run(c, 12)
+    for x, y in zip(c.engine.download(), want):
+        assert np.array_equal(x, y)
