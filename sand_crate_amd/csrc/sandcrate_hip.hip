@@ -78,9 +78,8 @@ struct sc_ctx {
   // particle sets: [0] storage order (input of a tick, output of pass B), [1] cell-sorted
   double *x[2] = {}, *y[2] = {}, *vx[2] = {}, *vy[2] = {};
   int* id[2] = {};
-  int *cellS = nullptr, *wslotS = nullptr, *cellT = nullptr, *wslotT = nullptr, *perm = nullptr;
-  double* keyX = nullptr;
-  int* keyId = nullptr;
+  int *cellS = nullptr, *wslotS = nullptr, *cellT = nullptr, *wslotT = nullptr;
+  SortKey* keys = nullptr;  // a bucket slot's (x, id, storage index): k_scatter writes, k_sort_big sorts, k_reorder ranks
   int* keyCell = nullptr;  // the packed cell of the particle in a bucket slot (k_scatter writes it next to the key)
   int* tileBounds = nullptr;   // per block of kTileW sorted particles: its three candidate ranges (k_reorder)
   int* tileBoundsT = nullptr;  // ... the three ranges its neighbor-table slots refer to (the search; sc_tiled.h)
@@ -92,8 +91,7 @@ struct sc_ctx {
   int band_epoch = 0;
   hipEvent_t ev_band = nullptr, ev_xchg = nullptr;
   int *cellCount = nullptr, *cellStart = nullptr, *blockSums = nullptr, *blockOff = nullptr, *sortedStamp = nullptr;
-  int* bigList = nullptr;
-  int* bigTable = nullptr;  // k_sort_big's task table (length, tasks before, per listed bucket): the scan builds it
+  int2* sortTasks = nullptr;  // k_sort_big's task list (cell, chunk | length): the scan writes it
   RcclComm comm = nullptr;  // RCCL communicator of the slab chain (sc_comm_init), or null
   int comm_rank = -1, comm_world = 0;
   double *haloL = nullptr, *haloR = nullptr;  // send buffers of the last sc_halo_pack (caller-owned device memory)
@@ -601,16 +599,13 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
   if (e == hipSuccess) e = dalloc(&c->wslotS, n);
   if (e == hipSuccess) e = dalloc(&c->cellT, n);
   if (e == hipSuccess) e = dalloc(&c->wslotT, n);
-  if (e == hipSuccess) e = dalloc(&c->perm, n);
-  if (e == hipSuccess) e = dalloc(&c->keyX, n);
-  if (e == hipSuccess) e = dalloc(&c->keyId, n);
+  if (e == hipSuccess) e = dalloc(&c->keys, n);
   if (e == hipSuccess) e = dalloc(&c->keyCell, n);
   if (e == hipSuccess) e = dalloc(&c->tileBounds, 6 * (n / kTileW + 2));
   if (e == hipSuccess) e = dalloc(&c->tileBoundsT, 6 * (n / kTileW + 2));
   if (e == hipSuccess) e = dalloc(&c->tileBand, n / kTileW + 2);
   if (e == hipSuccess) e = hipMemsetAsync(c->tileBand, 0, (n / kTileW + 2) * sizeof(int), c->stream);
-  if (e == hipSuccess) e = dalloc(&c->bigList, (size_t)kMaxBig);
-  if (e == hipSuccess) e = dalloc(&c->bigTable, (size_t)kBigTable);
+  if (e == hipSuccess) e = dalloc(&c->sortTasks, (size_t)kMaxSortTasks);
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->bigHintHost, kProgressInts * sizeof(int), hipHostMallocMapped);
   if (e == hipSuccess) {
     for (int k = 0; k < kProgressInts; ++k) c->bigHintHost[k] = 0;
@@ -650,7 +645,7 @@ int sc_destroy(sc_ctx* c) {
   }
   if (c->ev_band) (void)hipEventDestroy(c->ev_band);
   if (c->ev_xchg) (void)hipEventDestroy(c->ev_xchg);
-  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->perm, c->keyX, c->keyId, c->keyCell, c->tileBounds, c->tileBoundsT, c->tileBand, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->bigList, c->bigTable, c->wrec[0], c->wrec[1],
+  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->keys, c->keyCell, c->tileBounds, c->tileBoundsT, c->tileBand, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->sortTasks, c->wrec[0], c->wrec[1],
                   c->nbr, c->nbr16, c->cnt, c->P, c->snn, c->sxy, c->svv, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
                   c->stage_xy, c->stage_vxy, c->stage_ids, c->owned_out, c->colHist, c->rng, c->monitor,
                   c->snap_d[0], c->snap_d[1], c->snap_d[2], c->snap_d[3], c->snap_id_d, c->snap_rng_d};
@@ -804,29 +799,29 @@ int sc_step_begin(sc_ctx* c) {
     const int64_t ncells = (int64_t)w.nrows * w.ncols;
     const int nb = (int)((ncells + 1 + kScanPerBlock - 1) / kScanPerBlock);  // covers the one-past-the-end entry
     hipLaunchKernelGGL(k_scan_cells, dim3(nb), dim3(kBlock), 0, c->stream, c->cellCount, c->cellStart, (int)ncells,
-                       c->blockSums, c->blockOff, c->counters, c->bigList, c->bigHintDev, c->bigTable);
+                       c->blockSums, c->blockOff, c->counters, c->sortTasks, c->bigHintDev);
   }
   {
     Bracket br(c, K_SCATTER);
     if (piles_expected(c))
       hipLaunchKernelGGL(k_scatter<true>, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->cellS, c->x[0],
-                         c->id[0], Buckets{c->cellStart, c->blockOff}, c->cellCount, c->perm, c->keyX, c->keyId, c->keyCell, cap, w.live_hint);
+                         c->id[0], Buckets{c->cellStart, c->blockOff}, c->cellCount, c->keys, c->keyCell, cap, w.live_hint);
     else
       hipLaunchKernelGGL(k_scatter<false>, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->cellS, c->x[0],
-                         c->id[0], Buckets{c->cellStart, c->blockOff}, c->cellCount, c->perm, c->keyX, c->keyId, c->keyCell, cap, w.live_hint);
+                         c->id[0], Buckets{c->cellStart, c->blockOff}, c->cellCount, c->keys, c->keyCell, cap, w.live_hint);
   }
   const int stamp = (int)((c->tick + 1) & 0x3FFFFFFF);
   // big buckets were seen by the last scan the host knows about (an unsynchronised, possibly stale
   // hint in host-mapped memory): rank this tick's big buckets over the whole GPU first
   if (piles_expected(c)) {
     Bracket br(c, K_SCAN);
-    hipLaunchKernelGGL(k_sort_big, dim3(4 * c->num_cus), dim3(kSortBlock), 0, c->stream, c->counters, c->bigList,
-                       c->bigTable, Buckets{c->cellStart, c->blockOff}, c->keyX, c->keyId, c->perm, c->sortedStamp, stamp);
+    hipLaunchKernelGGL(k_sort_big, dim3(4 * c->num_cus), dim3(kSortBlock), 0, c->stream, c->counters, c->sortTasks,
+                       Buckets{c->cellStart, c->blockOff}, c->keys, c->sortedStamp, stamp);
   }
   {
     Bracket br(c, K_REORDER);
     hipLaunchKernelGGL(k_reorder, dim3((int)std::max<int64_t>(1, (launch_bound(c) + kReorderBlock - 1) / kReorderBlock)),
-                       dim3(kReorderBlock), 0, c->stream, c->counters, c->perm, c->keyX, c->keyId, c->keyCell,
+                       dim3(kReorderBlock), 0, c->stream, c->counters, c->keys, c->keyCell,
                        c->cellS, Buckets{c->cellStart, c->blockOff}, c->wslotS, c->y[0], c->vx[0], c->vy[0], c->sxy, c->svv,
                        c->id[1], c->cellT, c->wslotT, c->sortedStamp, stamp, w.ncols, c->tileBounds, w.live_hint);
   }

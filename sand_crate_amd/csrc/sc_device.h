@@ -98,7 +98,7 @@ enum Counter {
   C_SPARE8 = 8,
   C_TICKET = 9,  // workgroups that have finished the current halo kernel (last one publishes / bumps)
   C_NBIG = 10,   // buckets above kSortThreshold listed this tick
-  C_SPARE11 = 11,
+  C_NTASKS = 11, // ... and k_sort_big's tasks for them (one 64-bit atomic with C_NBIG: keep the two adjacent, C_NBIG even)
   C_COUNT = 12,
   // on cache lines of their own, away from the counters every workgroup reads (k_wait_band polls the flag):
   C_BAND_DONE = 32,  // halo overlap in one launch: the window blocks of the force kernel that have finished

@@ -300,11 +300,19 @@ constexpr int kSortBlock = SC_SORT_BLOCK;  // threads of a sorting task
 #endif
 constexpr int kSortChunk = SC_SORT_CHUNK;  // slots per sorting task (12 B of LDS per slot for the keys)
 constexpr int kSortBins = 256;         // bins of a chunk (by sampled splitters)
-constexpr int kRankMaxBuckets = 4096;  // big buckets sorted per tick = the room in the list (more: ranked in K4 by counting)
-constexpr int kBigTable = 3 * (kRankMaxBuckets + 1);  // k_sort_big's task table: (unused), length, tasks before, per bucket
-constexpr int kMaxBig = 4096;       // room in the list of big buckets
+constexpr int kMaxSortTasks = 16384;   // room in k_sort_big's task list (a bucket that does not fit is ranked in K4 by counting)
+static_assert(kSortChunk <= 2048, "a task packs its chunk's length - 1 into 11 bits");
 constexpr int kScanShift = 11;
 static_assert((1 << kScanShift) == kScanPerBlock, "block offset lookup assumes 2048 cells per scan block");
+
+// A bucket slot's sort key: the particle's x, its id (the tie-break) and its storage index, one 16-byte record -- written by
+// the scatter in one store, moved by k_sort_big in one, probed by K4's searches in one load (three arrays before: a
+// scrambled wave's scatter wrote 4 x 64 sectors, and a probe that hit an exact tie in x went back for the id).
+struct alignas(16) SortKey {
+  double x;
+  int id;
+  int src;
+};
 
 struct Buckets {
   const int* __restrict__ loc;
@@ -314,8 +322,8 @@ struct Buckets {
 
 __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ in, int* __restrict__ out, int n,
                                                        int* __restrict__ blockSums, int* __restrict__ blockOff,
-                                                       int* __restrict__ counters, int* __restrict__ bigList,
-                                                       volatile int* __restrict__ bigHint, int* __restrict__ bigTable) {
+                                                       int* __restrict__ counters, int2* __restrict__ sortTasks,
+                                                       volatile int* __restrict__ bigHint) {
   SC_TIMELINE_SCAN();
   __shared__ int waveTot[kBlock / 64];
   __shared__ int last;
@@ -329,9 +337,24 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
       int e = base + k < n ? in[base + k] : 0;
       v[k] = sum;
       sum += e;
-      if (e > kSortThreshold) {  // rare: a bucket worth sorting properly
-        int q = atomicAdd(&counters[C_NBIG], 1);
-        if (q < kMaxBig) __hip_atomic_store(&bigList[q], base + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // rare: a bucket worth sorting properly is cut into k_sort_big's tasks right here -- one task per chunk of kSortChunk
+      // slots, listed in whatever order the atomics hand out (the tasks are independent).  The wave's buckets share one
+      // 64-bit atomic (buckets in the low word, tasks in the high one: C_NBIG, C_NTASKS).  (The tasks used to be laid out
+      // by the last workgroup, alone on the GPU: 8 of the scan's 17 us in the pile-up regime.)
+      const bool bigc = e > kSortThreshold;
+      if (__ballot(bigc)) {
+        const int nt = bigc ? (e + kSortChunk - 1) / kSortChunk : 0;
+        const int incl_t = wave_scan_add(nt);
+        const unsigned long long m = __ballot(bigc);
+        const int total_t = __builtin_amdgcn_readlane(incl_t, 63);
+        unsigned long long got = 0;
+        if (lane == 0)
+          got = __hip_atomic_fetch_add((unsigned long long*)&counters[C_NBIG], (unsigned long long)__popcll(m) | ((unsigned long long)total_t << 32),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int first = __builtin_amdgcn_readfirstlane((int)(got >> 32)) + incl_t - nt;
+        const bool fits = first + nt <= kMaxSortTasks;
+        for (int j = 0; j < nt && first + j < kMaxSortTasks; ++j)  // a bucket cut off by the list's end: no-op tasks, ranked in K4
+          sortTasks[first + j] = make_int2(fits ? base + k : -1, j | ((min(kSortChunk, e - j * kSortChunk) - 1) << 20));
       }
     }
     const int incl = wave_scan_add(sum);
@@ -397,34 +420,6 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
     // synchronisation when the NEXT tick is enqueued and only decides whether k_sort_big is launched.
     bigHint[0] = nbig_all;
   }
-  // k_sort_big's task table, built once here: per listed bucket its length and the sorting tasks before it
-  const int nbig = min(nbig_all, kRankMaxBuckets);
-  if (nbig == 0) return;  // uniform
-  __syncthreads();        // blockOff is complete
-  int running = 0;        // tasks of the buckets before this round's 256
-  for (int q0 = 0; q0 < nbig; q0 += kBlock) {
-    const int q = q0 + threadIdx.x;
-    int t = 0;
-    if (q < nbig) {
-      const int c = __hip_atomic_load(&bigList[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int len = in[c];  // the bucket's size is its cell's count (the previous kernel's work); its start is the
-                              // other workgroups' `out`, which k_sort_big looks up itself
-      bigTable[(kRankMaxBuckets + 1) + q] = len;
-      t = (len + kSortChunk - 1) / kSortChunk;
-    }
-    const int incl = wave_scan_add(t);
-    __syncthreads();
-    if (lane == 63) waveTot[wv] = incl;
-    __syncthreads();
-    int wbase = 0, tot = 0;
-    for (int k = 0; k < kBlock / 64; ++k) {
-      if (k < wv) wbase += waveTot[k];
-      tot += waveTot[k];
-    }
-    if (q < nbig) bigTable[2 * (kRankMaxBuckets + 1) + q] = running + wbase + incl - t;
-    running += tot;
-  }
-  if (threadIdx.x == 0) bigTable[2 * (kRankMaxBuckets + 1) + nbig] = running;  // all tasks
 }
 
 // ------------------------------------------------------------------------------------------
@@ -451,11 +446,9 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
 __device__ __forceinline__ bool key_less(double xa, int ia, double xb, int ib) { return xa < xb || (xa == xb && ia < ib); }
 
 __global__ void __launch_bounds__(kSortBlock)
-    k_sort_big(const int* __restrict__ counters, const int* __restrict__ bigList, const int* __restrict__ bigTable,
-               Buckets bk, double* __restrict__ keyX, int* __restrict__ keyId, int* __restrict__ perm, int* __restrict__ sortedStamp,
-               int stamp) {
+    k_sort_big(const int* __restrict__ counters, const int2* __restrict__ sortTasks,
+               Buckets bk, SortKey* __restrict__ keys, int* __restrict__ sortedStamp, int stamp) {
   SC_TIMELINE_KERNEL(5);
-  __shared__ int pre[kRankMaxBuckets + 1];  // tasks before bucket q (the scan built the table)
   __shared__ double ox[kSortChunk];         // the chunk's keys in bin order
   __shared__ int oid[kSortChunk];
   __shared__ int hist[kSortBins + 1];       // bin sizes, then bin starts
@@ -464,19 +457,12 @@ __global__ void __launch_bounds__(kSortBlock)
   __shared__ int waveTot[kSortBins / 64];
   static_assert(kSortBins == 256 && kSortBlock >= kSortBins && kSortChunk % kSortBlock == 0, "the first 256 threads hold one sample / one bin each");
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int nbig = min(__hip_atomic_load(&counters[C_NBIG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), kRankMaxBuckets);
-  if (nbig == 0) return;
-  for (int q = tid; q <= nbig; q += kSortBlock) pre[q] = bigTable[2 * (kRankMaxBuckets + 1) + q];
-  __syncthreads();
-  const int total = pre[nbig];
+  const int total = min(__hip_atomic_load(&counters[C_NTASKS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), kMaxSortTasks);
   for (int task = blockIdx.x; task < total; task += gridDim.x) {
-    int lo = 0, hi = nbig;  // the bucket of this task: last q with pre[q] <= task
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (pre[mid] <= task) lo = mid; else hi = mid;
-    }
-    const int q = lo, local = task - pre[q];
-    const int b = bk(bigList[q]) + local * kSortChunk, len = min(kSortChunk, bigTable[(kRankMaxBuckets + 1) + q] - local * kSortChunk);
+    const int2 tk = sortTasks[task];  // the scan's list: (cell, chunk of its bucket | length of the chunk - 1)
+    const int cell = tk.x, local = tk.y & 0xFFFFF, len = (tk.y >> 20) + 1;
+    if (cell < 0) continue;  // workgroup-uniform: a bucket the list had no room for
+    const int b = bk(cell) + local * kSortChunk;
     SC_STAMP_VALUE(2, 8, len);
     SC_STAMP(2, 0);
     // 1. the chunk's keys, eight per thread
@@ -487,9 +473,10 @@ __global__ void __launch_bounds__(kSortBlock)
     for (int u = 0; u < kPerT; ++u) {
       const int e = tid + u * kSortBlock;
       if (e < len) {
-        x[u] = keyX[b + e];
-        id[u] = keyId[b + e];
-        pm[u] = perm[b + e];
+        const SortKey kk = keys[b + e];
+        x[u] = kk.x;
+        id[u] = kk.id;
+        pm[u] = kk.src;
       }
     }
     SC_STAMP(2, 1);
@@ -620,14 +607,12 @@ __global__ void __launch_bounds__(kSortBlock)
 #pragma unroll
           for (int k = 0; k < 4; ++k) r += (m + k < s1 && key_less(qx[k], qi[k], x[u], id[u])) ? 1 : 0;
         }
-        keyX[b + s0 + r] = x[u];
-        keyId[b + s0 + r] = id[u];
-        perm[b + s0 + r] = pm[u];
+        keys[b + s0 + r] = SortKey{x[u], id[u], pm[u]};
       }
     }
     SC_STAMP_LARGEST_BIN();
     SC_STAMP(2, 6);
-    if (local == 0 && tid == 0) sortedStamp[bigList[q]] = stamp;
+    if (local == 0 && tid == 0) sortedStamp[cell] = stamp;
   }
 }
 
@@ -657,8 +642,7 @@ template <bool GROUP>
 __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ counters, const int* __restrict__ cellS,
                                                     const double* __restrict__ xS, const int* __restrict__ idS,
                                                     Buckets bk, int* __restrict__ cellCount,
-                                                    int* __restrict__ perm, double* __restrict__ keyX,
-                                                    int* __restrict__ keyId, int* __restrict__ keyCell, int cap,
+                                                    SortKey* __restrict__ keys, int* __restrict__ keyCell, int cap,
                                                     int live_hint) {
   SC_TIMELINE_KERNEL(3);
   int i = chunk_of_block(live_hint) * blockDim.x + threadIdx.x;
@@ -707,9 +691,7 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ coun
     pos = base + (lane - run.head);
   }
   if (c < 0) return;
-  perm[pos] = i;
-  keyX[pos] = xi;
-  keyId[pos] = idi;
+  keys[pos] = SortKey{xi, idi, i};
   keyCell[pos] = cpacked;  // K4 finds the ends of a small bucket from its neighbors' cells instead of looking them up
 }
 
@@ -728,16 +710,14 @@ constexpr int kReorderBlock = 64; // one wave per workgroup: a big bucket is sha
 constexpr int kRankWindow = 12;   // slots either side of a particle in which a small bucket's ends are looked for
 
 __global__ void __launch_bounds__(kReorderBlock)
-    k_reorder(const int* __restrict__ counters, const int* __restrict__ perm, const double* __restrict__ keyX,
-              const int* __restrict__ keyId, const int* __restrict__ keyCell, const int* __restrict__ cellS, Buckets bk,
+    k_reorder(const int* __restrict__ counters, const SortKey* __restrict__ keys, const int* __restrict__ keyCell, const int* __restrict__ cellS, Buckets bk,
               const int* __restrict__ wslotS, const double* __restrict__ yS, const double* __restrict__ vxS,
               const double* __restrict__ vyS, XY* __restrict__ xyT, XY* __restrict__ vvT, int* __restrict__ idT,
               int* __restrict__ cellT,
               int* __restrict__ wslotT, const int* __restrict__ sortedStamp, int stamp, int ncols,
               int* __restrict__ tileBounds, int live_hint) {
   SC_TIMELINE_KERNEL(4);
-  __shared__ double ckx[kRankChunk];
-  __shared__ int cki[kRankChunk];
+  __shared__ SortKey ck[kRankChunk];
   __shared__ int wcell[kReorderBlock + 2 * kRankWindow];
   __shared__ int pick;
   static_assert(kReorderBlock + 2 * kRankWindow <= kRankChunk && 2 * kRankWindow - 1 <= kBigBucket, "window fits, and what it resolves is a small bucket");
@@ -752,7 +732,12 @@ __global__ void __launch_bounds__(kReorderBlock)
   // leaves the cell next to the key and the workgroup reads the keys and cells of its 64 slots and kRankWindow slots
   // either side in one coalesced sweep: a bucket whose two ends show inside the window (nearly all: a cell holds 4
   // particles on average) is ranked from LDS while the gathers by storage index are still in flight.
-  if (live) i = perm[s];
+  if (live) {  // the thread's own key first: the gathers by storage index hang on it
+    const SortKey own = keys[s];
+    xi = own.x;
+    idi = own.id;
+    i = own.src;
+  }
   {
     const int s0 = s - (int)threadIdx.x;
     for (int w = threadIdx.x; w < kReorderBlock + 2 * kRankWindow; w += kReorderBlock) {
@@ -760,8 +745,7 @@ __global__ void __launch_bounds__(kReorderBlock)
       const bool ok = slot >= 0 && slot < nlive;
       const int sl = ok ? slot : s0;
       const int cw = keyCell[sl];
-      ckx[w] = keyX[sl];
-      cki[w] = keyId[sl];
+      ck[w] = keys[sl];
       wcell[w] = ok ? cw : -1;  // packed (ghost bit and all); -1: no slot
     }
   }
@@ -778,8 +762,6 @@ __global__ void __launch_bounds__(kReorderBlock)
     const int w0 = threadIdx.x + kRankWindow;
     cpacked = wcell[w0];
     c = cpacked & kCellMask;
-    xi = ckx[w0];
-    idi = cki[w0];
     auto same = [&](int v) { return v >= 0 && (v & kCellMask) == c; };
     int nl = 0, nr = 0;  // slots of the same cell to the left / right
     while (nl < kRankWindow && same(wcell[w0 - nl - 1])) ++nl;
@@ -789,8 +771,8 @@ __global__ void __launch_bounds__(kReorderBlock)
       b = s - nl;
       e = s + nr + 1;
       for (int w = w0 - nl; w <= w0 + nr; ++w) {
-        const double kx = ckx[w];
-        rank += (kx < xi) || (kx == xi && cki[w] < idi);
+        const SortKey kk = ck[w];
+        rank += (kk.x < xi) || (kk.x == xi && kk.id < idi);
       }
     } else {
       cpacked = cellS[i];  // k_sort_big moves keys and storage indices inside a bucket, not the cells next to them
@@ -798,35 +780,60 @@ __global__ void __launch_bounds__(kReorderBlock)
       e = bk(c + 1);
     }
   }
-  __syncthreads();  // the window is read; ckx / cki serve the big buckets below
+  __syncthreads();  // the window is read; ck serves the big buckets below
   // a bucket k_sort_big has sorted this tick, chunk by chunk: the rank is the position inside the particle's chunk
   // plus the keys below (x, id) in each of the bucket's other chunks
   const bool presorted = live && !resolved && (e - b) > kSortThreshold && sortedStamp[c] == stamp;
   if (presorted) {
-    const int mine = (s - b) / kSortChunk;
+    const int mine = (s - b) / kSortChunk, nch = (e - b + kSortChunk - 1) / kSortChunk;
     rank = (s - b) - mine * kSortChunk;
-    for (int cb = b, r = 0; cb < e; cb += kSortChunk, ++r) {
-      if (r == mine) continue;
-      int lo = cb, hi = min(cb + kSortChunk, e);  // first key of the chunk that is not below (x, id)
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        const double xm = keyX[mid];
-        if (xm < xi || (xm == xi && keyId[mid] < idi)) lo = mid + 1; else hi = mid;
+    // the searches of up to four other chunks advance together, key and id of a probe requested at once: a step is ONE
+    // round trip whatever the number of chunks and of exact ties in x (one chunk after the other, the id fetched only on a
+    // tie -- the rule in a pile stopped on a wall -- a bucket of 4000 was a chain of 60 round trips: the kernel's tail)
+    constexpr int kSide = 4;
+    for (int r0 = 0; r0 < nch; r0 += kSide) {
+      int lo[kSide], hi[kSide];
+#pragma unroll
+      for (int u = 0; u < kSide; ++u) {
+        const int r = r0 + u, cb = b + r * kSortChunk;
+        lo[u] = cb;
+        hi[u] = (r < nch && r != mine) ? min(cb + kSortChunk, e) : cb;  // nothing to search: an empty range
       }
-      rank += lo - cb;
+      while ((lo[0] < hi[0]) | (lo[1] < hi[1]) | (lo[2] < hi[2]) | (lo[3] < hi[3])) {
+        double xm[kSide];
+        int im[kSide], mid[kSide];
+#pragma unroll
+        for (int u = 0; u < kSide; ++u) {
+          mid[u] = (lo[u] + hi[u]) >> 1;
+          xm[u] = 0.0;
+          im[u] = 0;
+          if (lo[u] < hi[u]) {
+            const SortKey kk = keys[mid[u]];
+            xm[u] = kk.x;
+            im[u] = kk.id;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kSide; ++u) {
+          if (lo[u] < hi[u]) {  // first key of the chunk that is not below (x, id)
+            if (key_less(xm[u], im[u], xi, idi)) lo[u] = mid[u] + 1; else hi[u] = mid[u];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kSide; ++u) rank += lo[u] - (b + (r0 + u) * kSortChunk);
     }
   }
   const bool big = live && !resolved && !presorted && (e - b) > kBigBucket;
   if (live && !resolved && !big && !presorted) {
     for (int t = b; t < e; t += 4) {  // four keys in flight per round trip
-      double k0 = keyX[t], k1 = t + 1 < e ? keyX[t + 1] : xi, k2 = t + 2 < e ? keyX[t + 2] : xi,
-             k3 = t + 3 < e ? keyX[t + 3] : xi;
-      int d0 = keyId[t], d1 = t + 1 < e ? keyId[t + 1] : idi, d2 = t + 2 < e ? keyId[t + 2] : idi,
-          d3 = t + 3 < e ? keyId[t + 3] : idi;
-      rank += (k0 < xi) || (k0 == xi && d0 < idi);
-      rank += (k1 < xi) || (k1 == xi && d1 < idi);
-      rank += (k2 < xi) || (k2 == xi && d2 < idi);
-      rank += (k3 < xi) || (k3 == xi && d3 < idi);
+      const SortKey own{xi, idi, 0};  // a slot past the bucket's end counts as the particle itself: not below it
+      const SortKey k0 = keys[t], k1 = t + 1 < e ? keys[t + 1] : own, k2 = t + 2 < e ? keys[t + 2] : own,
+                    k3 = t + 3 < e ? keys[t + 3] : own;
+      rank += key_less(k0.x, k0.id, xi, idi);
+      rank += key_less(k1.x, k1.id, xi, idi);
+      rank += key_less(k2.x, k2.id, xi, idi);
+      rank += key_less(k3.x, k3.id, xi, idi);
     }
   }
   // Buckets of thousands (particles piled up against a wall, many with exactly equal x) would cost
@@ -848,15 +855,12 @@ __global__ void __launch_bounds__(kReorderBlock)
     for (int base = cb; base < ce; base += kRankChunk) {
       const int len = min(kRankChunk, ce - base);
       __syncthreads();
-      for (int k = threadIdx.x; k < len; k += kReorderBlock) {
-        ckx[k] = keyX[base + k];
-        cki[k] = keyId[base + k];
-      }
+      for (int k = threadIdx.x; k < len; k += kReorderBlock) ck[k] = keys[base + k];
       __syncthreads();
       if (mine) {
         for (int k = 0; k < len; ++k) {
-          const double kx = ckx[k];
-          rank += (kx < xi) || (kx == xi && cki[k] < idi);
+          const SortKey kk = ck[k];
+          rank += (kk.x < xi) || (kk.x == xi && kk.id < idi);
         }
       }
     }

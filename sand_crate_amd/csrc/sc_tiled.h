@@ -1020,6 +1020,7 @@ __global__ void __launch_bounds__(kTileW)
     counters[C_SUMC_HI] = 0;
     counters[C_MAXC] = 0;
     counters[C_NBIG] = 0;
+    counters[C_NTASKS] = 0;
     SC_TIMELINE_EPOCH(w.tick + 1);
     progress[1] = w.tick + 1;  // host-mapped: the host keeps at most a few ticks of launches queued
     progress[2] = n;           // ... and sizes heuristics by a recent live count
