@@ -41,7 +41,7 @@ __device__ __forceinline__ int pairs_b(int C) { return kCapB >= kMaxNbr ? C : mi
 // on the host); the product build compiles none of this.
 #ifdef SC_STAMPS
 constexpr int kStampSlots = 24, kStampWaves = 1 << 16;
-constexpr int kStampKernels = 4;  // 0: pass A, 1: pass B (even ticks), 2: k_sort_big, 3: pass B (odd ticks)
+constexpr int kStampKernels = 6;  // 0: pass A, 1: pass B (even ticks), 2: k_sort_big, 3: pass B (odd ticks), 4: scatter, 5: reorder
 __device__ long long g_stamps[kStampKernels][kStampWaves][kStampSlots];
 #define SC_STAMP(kernel, slot)                                                                          \
   do {                                                                                                   \

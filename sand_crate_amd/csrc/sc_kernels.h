@@ -300,7 +300,10 @@ constexpr int kSortBlock = SC_SORT_BLOCK;  // threads of a sorting task
 #endif
 constexpr int kSortChunk = SC_SORT_CHUNK;  // slots per sorting task (12 B of LDS per slot for the keys)
 constexpr int kSortBins = 256;         // bins of a chunk (by sampled splitters)
-constexpr int kMaxSortTasks = 16384;   // room in k_sort_big's task list (a bucket that does not fit is ranked in K4 by counting)
+#ifndef SC_MAX_SORT_TASKS
+#define SC_MAX_SORT_TASKS 16384
+#endif
+constexpr int kMaxSortTasks = SC_MAX_SORT_TASKS;   // room in k_sort_big's task list (a bucket that does not fit is ranked in K4 by counting)
 static_assert(kSortChunk <= 2048, "a task packs its chunk's length - 1 into 11 bits");
 constexpr int kScanShift = 11;
 static_assert((1 << kScanShift) == kScanPerBlock, "block offset lookup assumes 2048 cells per scan block");
@@ -651,8 +654,10 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ coun
   const int cpacked = c;
   const double xi = xS[ic];
   const int idi = idS[ic];
+  SC_STAMP(4, 0);
   if (i >= counters[C_NS]) c = -1;
   if (c >= 0) c &= kCellMask;
+  SC_STAMP(4, 1);
   const int lane = threadIdx.x & 63;
   // Storage order is the previous tick's sorted order, so the lanes of a run share a cell -- as long as particles
   // stay near their cells.  In a pile-up they do not (the contract workload's particles cross more than a cell per
@@ -680,6 +685,7 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ coun
       my_leader = lane;
       my_len = 1;
     }
+    SC_STAMP(4, 2);
     int base = 0;  // the groups' atomics leave together
     if (my_leader == lane) base = bk(c) + atomicSub(&cellCount[c], my_len) - my_len;
     base = __shfl(base, my_leader >= 0 ? my_leader : lane, 64);
@@ -690,9 +696,12 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ coun
     base = __shfl(base, run.head, 64);
     pos = base + (lane - run.head);
   }
-  if (c < 0) return;
-  keys[pos] = SortKey{xi, idi, i};
-  keyCell[pos] = cpacked;  // K4 finds the ends of a small bucket from its neighbors' cells instead of looking them up
+  SC_STAMP(4, 3);
+  if (c >= 0) {
+    keys[pos] = SortKey{xi, idi, i};
+    keyCell[pos] = cpacked;  // K4 finds the ends of a small bucket from its neighbors' cells instead of looking them up
+  }
+  SC_STAMP(4, 4);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -722,6 +731,7 @@ __global__ void __launch_bounds__(kReorderBlock)
   __shared__ int pick;
   static_assert(kReorderBlock + 2 * kRankWindow <= kRankChunk && 2 * kRankWindow - 1 <= kBigBucket, "window fits, and what it resolves is a small bucket");
   const int s = chunk_of_block(live_hint) * blockDim.x + threadIdx.x;
+  SC_STAMP(5, 0);
   const int nlive = counters[C_NT];
   if (s - (int)threadIdx.x >= nlive) return;  // a block beyond the live particles (a slab's grid covers its capacity)
   const bool live = s < nlive;
@@ -756,23 +766,35 @@ __global__ void __launch_bounds__(kReorderBlock)
     wsi = wslotS[i];
   }
   __syncthreads();
+  SC_STAMP(5, 1);
   int rank = 0;
   bool resolved = false;
   if (live) {
     const int w0 = threadIdx.x + kRankWindow;
     cpacked = wcell[w0];
     c = cpacked & kCellMask;
-    auto same = [&](int v) { return v >= 0 && (v & kCellMask) == c; };
-    int nl = 0, nr = 0;  // slots of the same cell to the left / right
-    while (nl < kRankWindow && same(wcell[w0 - nl - 1])) ++nl;
-    while (nr < kRankWindow && same(wcell[w0 + nr + 1])) ++nr;
+    // the slots of the same cell next to this one: all 24 cells of the window are read at once and the two runs are counted
+    // in registers, then the bucket's keys four per step (three loops of dependent LDS reads, one per slot, were a third
+    // of this kernel's wave life)
+    unsigned ml = 0, mr = 0;
+#pragma unroll
+    for (int k = 0; k < kRankWindow; ++k) {
+      const int vl = wcell[w0 - 1 - k], vr = wcell[w0 + 1 + k];
+      ml |= (unsigned)(vl >= 0 && (vl & kCellMask) == c) << k;
+      mr |= (unsigned)(vr >= 0 && (vr & kCellMask) == c) << k;
+    }
+    const int nl = __builtin_ctz(~ml), nr = __builtin_ctz(~mr);  // at most kRankWindow: bit 12 of ~m is set
     resolved = nl < kRankWindow && nr < kRankWindow;
     if (resolved) {
       b = s - nl;
       e = s + nr + 1;
-      for (int w = w0 - nl; w <= w0 + nr; ++w) {
-        const SortKey kk = ck[w];
-        rank += (kk.x < xi) || (kk.x == xi && kk.id < idi);
+      const int wl = w0 + nr;
+      for (int w = w0 - nl; w <= wl; w += 4) {
+        SortKey q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = ck[min(w + k, wl)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rank += (w + k <= wl) && key_less(q[k].x, q[k].id, xi, idi);
       }
     } else {
       cpacked = cellS[i];  // k_sort_big moves keys and storage indices inside a bucket, not the cells next to them
@@ -780,6 +802,7 @@ __global__ void __launch_bounds__(kReorderBlock)
       e = bk(c + 1);
     }
   }
+  SC_STAMP(5, 2);
   __syncthreads();  // the window is read; ck serves the big buckets below
   // a bucket k_sort_big has sorted this tick, chunk by chunk: the rank is the position inside the particle's chunk
   // plus the keys below (x, id) in each of the bucket's other chunks
@@ -824,6 +847,7 @@ __global__ void __launch_bounds__(kReorderBlock)
       for (int u = 0; u < kSide; ++u) rank += lo[u] - (b + (r0 + u) * kSortChunk);
     }
   }
+  SC_STAMP(5, 3);
   const bool big = live && !resolved && !presorted && (e - b) > kBigBucket;
   if (live && !resolved && !big && !presorted) {
     for (int t = b; t < e; t += 4) {  // four keys in flight per round trip
@@ -841,6 +865,7 @@ __global__ void __launch_bounds__(kReorderBlock)
   // buckets together instead: their keys stream through LDS in coalesced chunks and every thread of
   // the bucket compares against the chunk with broadcast LDS reads.  A workgroup holds consecutive
   // slots, so it sees at most a handful of distinct buckets, taken one at a time.
+  SC_STAMP(5, 4);
   bool pending = big;
   while (true) {
     __syncthreads();
@@ -866,6 +891,7 @@ __global__ void __launch_bounds__(kReorderBlock)
     }
     if (mine) pending = false;
   }
+  SC_STAMP(5, 5);
   if (!live) return;
   const int dst = b + rank;
   // The candidates of a block of SC_TILE_W consecutive sorted particles lie in three index ranges (sc_tiled.h);
@@ -888,6 +914,7 @@ __global__ void __launch_bounds__(kReorderBlock)
   idT[dst] = idi;
   cellT[dst] = cpacked;
   wslotT[dst] = wsi;
+  SC_STAMP(5, 6);
 }
 
 // K5-K7 (neighbor search, pass A, pass B) are the LDS-tiled kernels of sc_tiled.h.

@@ -13,7 +13,7 @@ p, v = bench.synthetic_state(n)
 s.particles = p; s.particle_velocities = v
 s.run(T); s.synchronize()
 lib = N.load()
-buf = np.zeros((4, 1 << 16, 24), dtype=np.int64)
+buf = np.zeros((6, 1 << 16, 24), dtype=np.int64)
 lib.sc_debug_stamps.restype = C.c_int
 lib.sc_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
 assert lib.sc_debug_stamps(s.engine._ctx, buf.ctypes.data_as(C.c_void_p)) == 0

@@ -1,0 +1,42 @@
+"""Where a wave of the scatter and of K4 (reorder) spends its life (diagnostic build with -DSC_STAMPS), at a tick of the
+uniform regime or deep in the pile-up.   python scripts/sort_stamps.py [particles] [ticks before the stamped one]"""
+import copy, ctypes as C, sys
+sys.path.insert(0, ".")
+import numpy as np
+import bench, sand_crate_amd as sc
+from sand_crate_amd import _native as N
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1048576
+ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+wc, d = bench.world_for(n)
+s = sc.Crate(copy.deepcopy(wc), noise="counter", noise_seed=1, capacity=n + 1024)
+p, v = bench.synthetic_state(n)
+s.particles = p; s.particle_velocities = v
+s.run(ticks); s.synchronize()
+lib = N.load()
+buf = np.zeros((6, 1 << 16, 24), dtype=np.int64)
+lib.sc_debug_stamps.restype = C.c_int
+lib.sc_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
+assert lib.sc_debug_stamps(s.engine._ctx, buf.ctypes.data_as(C.c_void_p)) == 0
+waves = (n + 63) // 64
+def show(k, title, cols, names):
+    st = buf[k, :waves]
+    ok = (st[:, cols] > 0).all(axis=1)
+    if not ok.any():
+        return print(f"{title}: no such waves")
+    sel = st[ok][:, cols]
+    dt = np.diff(sel, axis=1)
+    life = sel[:, -1] - sel[:, 0]
+    print(f"{title}: {ok.sum()} waves with every stamp, wave life median {np.median(life):.0f} mean {life.mean():.0f} p95 {np.percentile(life, 95):.0f} cycles")
+    for j, label in enumerate(names):
+        print(f"    {label:44s} median {np.median(dt[:, j]):8.0f}   mean {dt[:, j].mean():8.0f}   p95 {np.percentile(dt[:, j], 95):8.0f}   p99 {np.percentile(dt[:, j], 99):8.0f}")
+# a wave of the scatter that is not scrambled never takes stamp 2: report the two kinds apart
+st = buf[4, :waves]
+scr = st[:, 2] > st[:, 1]
+print(f"scatter: {scr.sum()} of {waves} waves grouped their lanes by cell (scrambled)")
+keep = buf[4, :waves].copy()
+buf[4, :waves][~scr] = 0
+show(4, "scatter, scrambled waves", [0, 1, 2, 3, 4], ["cell, x, id, live count loaded", "lanes grouped by cell (12 rounds)", "bucket starts + returning atomics", "key and cell stored"])
+buf[4, :waves] = keep
+buf[4, :waves][scr] = 0
+show(4, "scatter, waves in runs", [0, 1, 3, 4], ["cell, x, id, live count loaded", "runs, bucket starts + returning atomics", "key and cell stored"])
+show(5, "reorder", [0, 1, 2, 3, 4, 5, 6], ["own key, window swept, gathers back", "ranked inside the window", "searches in a sorted bucket's other chunks", "small bucket outside the window", "big unsorted buckets, workgroup-wide", "stores"])
