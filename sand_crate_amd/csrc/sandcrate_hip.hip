@@ -90,7 +90,9 @@ struct sc_ctx {
   bool band_flagged = false;  // the pending band is announced by the flag (k_wait_band), not by ev_band
   int band_epoch = 0;
   hipEvent_t ev_band = nullptr, ev_xchg = nullptr;
-  int *cellCount = nullptr, *cellStart = nullptr, *blockSums = nullptr, *blockOff = nullptr, *sortedStamp = nullptr;
+  int *cellCount = nullptr, *cellStart = nullptr, *sortedStamp = nullptr;
+  unsigned long long* scanDesc = nullptr;  // the bucket scan's look-back descriptors, one per 2048 cells (k_scan_cells)
+  unsigned scanStamp = 0;                  // ... and the stamp of its last launch
   int2* sortTasks = nullptr;  // k_sort_big's task list (cell, chunk | length): the scan writes it
   RcclComm comm = nullptr;  // RCCL communicator of the slab chain (sc_comm_init), or null
   int comm_rank = -1, comm_world = 0;
@@ -221,14 +223,13 @@ int ensure_cells(sc_ctx* c, int64_t ncells) {
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->cellCount) (void)hipFree(c->cellCount);
   if (c->cellStart) (void)hipFree(c->cellStart);
-  if (c->blockSums) (void)hipFree(c->blockSums);
-  if (c->blockOff) (void)hipFree(c->blockOff);
+  if (c->scanDesc) (void)hipFree(c->scanDesc);
   if (c->sortedStamp) (void)hipFree(c->sortedStamp);
   int64_t n = ncells + 1 + ncells / 4;
   HIPCHK(dalloc(&c->cellCount, n));
   HIPCHK(dalloc(&c->cellStart, n + 1));
-  HIPCHK(dalloc(&c->blockSums, n / kScanPerBlock + 4));
-  HIPCHK(dalloc(&c->blockOff, n / kScanPerBlock + 4));
+  HIPCHK(dalloc(&c->scanDesc, n / kScanPerBlock + 4));
+  HIPCHK(hipMemsetAsync(c->scanDesc, 0, (n / kScanPerBlock + 4) * sizeof(unsigned long long), c->stream));  // stamp 0: never launched
   HIPCHK(dalloc(&c->sortedStamp, n));
   HIPCHK(hipMemsetAsync(c->sortedStamp, 0, n * sizeof(int), c->stream));
   HIPCHK(hipMemsetAsync(c->cellCount, 0, n * sizeof(int), c->stream));
@@ -405,6 +406,8 @@ int check_flags(int flags) {
   if (flags & F_CAPACITY) return fail(SC_ERR_CAPACITY, "received halo particles exceed the context capacity");
   if (flags & F_BAND_TIMEOUT)
     return fail(SC_ERR_HIP, "the halo exchange waited 50 ms for the band blocks of the force kernel and gave up");
+  if (flags & F_SCAN_TIMEOUT)
+    return fail(SC_ERR_HIP, "the bucket scan waited for a workgroup that never published its total and gave up");
   if (flags & F_HALO_LATE)
     return fail(SC_ERR_DOMAIN, "a particle moved more than the band margin (%d columns / %d rows) in one tick and missed the "
                 "overlapped halo message: run without halo overlap", kBandMarginColumns, kBandMarginRows);
@@ -472,7 +475,7 @@ template <int NOISE, bool ENUM, bool DENS, int CAP>
 void launch_pass_a_cap(sc_ctx* c) {
   auto launch = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters,
-                       c->sxy, c->id[1], c->cellT, Buckets{c->cellStart, c->blockOff}, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta, c->offById,
+                       c->sxy, c->id[1], c->cellT, Buckets{c->cellStart}, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta, c->offById,
                        c->P, c->snn, ENUM ? c->tileBounds : c->tileBoundsT, c->tileBand, c->tileBoundsT);
   };
   if (ENUM && DENS && piles_expected(c))  // dense tiles ahead: the instantiation that stages their lists' reach
@@ -645,7 +648,7 @@ int sc_destroy(sc_ctx* c) {
   }
   if (c->ev_band) (void)hipEventDestroy(c->ev_band);
   if (c->ev_xchg) (void)hipEventDestroy(c->ev_xchg);
-  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->keys, c->keyCell, c->tileBounds, c->tileBoundsT, c->tileBand, c->cellCount, c->cellStart, c->blockSums, c->blockOff, c->sortedStamp, c->sortTasks, c->wrec[0], c->wrec[1],
+  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->keys, c->keyCell, c->tileBounds, c->tileBoundsT, c->tileBand, c->cellCount, c->cellStart, c->scanDesc, c->sortedStamp, c->sortTasks, c->wrec[0], c->wrec[1],
                   c->nbr, c->nbr16, c->cnt, c->P, c->snn, c->sxy, c->svv, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
                   c->stage_xy, c->stage_vxy, c->stage_ids, c->owned_out, c->colHist, c->rng, c->monitor,
                   c->snap_d[0], c->snap_d[1], c->snap_d[2], c->snap_d[3], c->snap_id_d, c->snap_rng_d};
@@ -798,17 +801,18 @@ int sc_step_begin(sc_ctx* c) {
     Bracket br(c, K_SCAN);
     const int64_t ncells = (int64_t)w.nrows * w.ncols;
     const int nb = (int)((ncells + 1 + kScanPerBlock - 1) / kScanPerBlock);  // covers the one-past-the-end entry
+    c->scanStamp = c->scanStamp % 0x3FFFFFFFu + 1;  // 1 .. 2^30 - 1: never the cleared descriptors' 0
     hipLaunchKernelGGL(k_scan_cells, dim3(nb), dim3(kBlock), 0, c->stream, c->cellCount, c->cellStart, (int)ncells,
-                       c->blockSums, c->blockOff, c->counters, c->sortTasks, c->bigHintDev);
+                       c->scanDesc, c->scanStamp, c->counters, c->sortTasks);
   }
   {
     Bracket br(c, K_SCATTER);
     if (piles_expected(c))
       hipLaunchKernelGGL(k_scatter<true>, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->cellS, c->x[0],
-                         c->id[0], Buckets{c->cellStart, c->blockOff}, c->cellCount, c->keys, c->keyCell, cap, w.live_hint);
+                         c->id[0], Buckets{c->cellStart}, c->cellCount, c->keys, c->keyCell, cap, w.live_hint);
     else
       hipLaunchKernelGGL(k_scatter<false>, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->cellS, c->x[0],
-                         c->id[0], Buckets{c->cellStart, c->blockOff}, c->cellCount, c->keys, c->keyCell, cap, w.live_hint);
+                         c->id[0], Buckets{c->cellStart}, c->cellCount, c->keys, c->keyCell, cap, w.live_hint);
   }
   const int stamp = (int)((c->tick + 1) & 0x3FFFFFFF);
   // big buckets were seen by the last scan the host knows about (an unsynchronised, possibly stale
@@ -816,14 +820,14 @@ int sc_step_begin(sc_ctx* c) {
   if (piles_expected(c)) {
     Bracket br(c, K_SCAN);
     hipLaunchKernelGGL(k_sort_big, dim3(4 * c->num_cus), dim3(kSortBlock), 0, c->stream, c->counters, c->sortTasks,
-                       Buckets{c->cellStart, c->blockOff}, c->keys, c->sortedStamp, stamp);
+                       Buckets{c->cellStart}, c->keys, c->sortedStamp, stamp);
   }
   {
     Bracket br(c, K_REORDER);
     hipLaunchKernelGGL(k_reorder, dim3((int)std::max<int64_t>(1, (launch_bound(c) + kReorderBlock - 1) / kReorderBlock)),
                        dim3(kReorderBlock), 0, c->stream, c->counters, c->keys, c->keyCell,
-                       c->cellS, Buckets{c->cellStart, c->blockOff}, c->wslotS, c->y[0], c->vx[0], c->vy[0], c->sxy, c->svv,
-                       c->id[1], c->cellT, c->wslotT, c->sortedStamp, stamp, w.ncols, c->tileBounds, w.live_hint);
+                       c->cellS, Buckets{c->cellStart}, c->wslotS, c->y[0], c->vx[0], c->vy[0], c->sxy, c->svv,
+                       c->id[1], c->cellT, c->wslotT, c->sortedStamp, stamp, w.ncols, c->tileBounds, w.live_hint, c->bigHintDev);
   }
   // SC_NOISE_HOST (and the stand-alone search) stop after the lists: the host's rand block can only be
   // indexed once every count is known.  Otherwise the search and pass A are one launch.

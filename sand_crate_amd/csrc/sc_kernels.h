@@ -294,10 +294,14 @@ __global__ void __launch_bounds__(kBlock) k_scan_fix(int* __restrict__ out, int 
   }
 }
 
-// Bucket starts in ONE launch.  They are kept in two levels -- the start of a cell inside its
-// 2048-cell block (cellStart) and the start of the block (blockOff) -- so that no second pass over
-// the cells is needed: every workgroup scans its block, and the last one to finish (ticket) scans
-// the block totals.  Readers add the two (struct Buckets).  Saves a ~5 us launch per tick.
+// Bucket starts in ONE launch and one level: a single-pass scan with decoupled look-back.  Every workgroup scans its
+// 2048 counts, publishes their total (a descriptor: launch stamp, state, value in one 64-bit word, stored past the XCD's
+// L2), looks back over the descriptors of the workgroups before it -- 64 at a time, down to the nearest one that already
+// knows its own prefix -- publishes its prefix and writes global bucket starts.  (Round 2 kept two levels -- a start inside
+// the block and block offsets that the last workgroup to draw a ticket scanned alone on the GPU: a returning atomic, a
+// fence and two more round trips on the critical path of a 7.5 us kernel, and a second load in every bucket lookup.)
+// The stamp changes with every launch, so the descriptors are never cleared.  A workgroup waits for lower block indices
+// only, which the dispatcher starts first; the wait is bounded all the same (F_SCAN_TIMEOUT).
 constexpr int kSortThreshold = 96;  // buckets above this many particles are listed for k_sort_big
 #ifndef SC_SORT_BLOCK
 #define SC_SORT_BLOCK 256
@@ -313,8 +317,6 @@ constexpr int kSortBins = 256;         // bins of a chunk (by sampled splitters)
 #endif
 constexpr int kMaxSortTasks = SC_MAX_SORT_TASKS;   // room in k_sort_big's task list (a bucket that does not fit is ranked in K4 by counting)
 static_assert(kSortChunk <= 2048, "a task packs its chunk's length - 1 into 11 bits");
-constexpr int kScanShift = 11;
-static_assert((1 << kScanShift) == kScanPerBlock, "block offset lookup assumes 2048 cells per scan block");
 
 // A bucket slot's sort key: the particle's x, its id (the tie-break) and its storage index, one 16-byte record -- written by
 // the scatter in one store, moved by k_sort_big in one, probed by K4's searches in one load (three arrays before: a
@@ -326,111 +328,118 @@ struct alignas(16) SortKey {
 };
 
 struct Buckets {
-  const int* __restrict__ loc;
-  const int* __restrict__ off;
-  __device__ __forceinline__ int operator()(int c) const { return loc[c] + off[c >> kScanShift]; }
+  const int* __restrict__ start;
+  __device__ __forceinline__ int operator()(int c) const { return start[c]; }
 };
 
+constexpr unsigned kDescTotal = 1, kDescPrefix = 2;  // a descriptor's state: the block's own total / the total of all blocks up to it
+constexpr int kScanMaxPolls = 1 << 22;
+__device__ __forceinline__ unsigned long long scan_desc(unsigned stamp, unsigned state, int value) {
+  return ((unsigned long long)((stamp << 2) | state) << 32) | (unsigned)value;
+}
+
 __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ in, int* __restrict__ out, int n,
-                                                       int* __restrict__ blockSums, int* __restrict__ blockOff,
-                                                       int* __restrict__ counters, int2* __restrict__ sortTasks,
-                                                       volatile int* __restrict__ bigHint) {
+                                                       unsigned long long* __restrict__ desc, unsigned stamp,
+                                                       int* __restrict__ counters, int2* __restrict__ sortTasks) {
   SC_TIMELINE_SCAN();
-  __shared__ int waveTot[kBlock / 64];
-  __shared__ int last;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  {
-    int base = blockIdx.x * kScanPerBlock + threadIdx.x * kScanPerThread;
-    int v[kScanPerThread];
-    int sum = 0;
+  __shared__ int waveTot[kBlock / 64], waveTasks[kBlock / 64], waveBig[kBlock / 64];
+  __shared__ int blockBase, taskBase;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, blk = blockIdx.x;
+  const int base = blk * kScanPerBlock + threadIdx.x * kScanPerThread;
+  int v[kScanPerThread];
+  int sum = 0, my_big = 0, my_tasks = 0;
+#pragma unroll
+  for (int k = 0; k < kScanPerThread; ++k) {
+    int e = base + k < n ? in[base + k] : 0;
+    v[k] = sum;
+    sum += e;
+    if (e > kSortThreshold) {  // rare: a bucket worth sorting properly
+      ++my_big;
+      my_tasks += (e + kSortChunk - 1) / kSortChunk;
+    }
+  }
+  // Such buckets are cut into k_sort_big's tasks right here -- one task per chunk of kSortChunk slots, listed in whatever
+  // order the atomics hand out (the tasks are independent).  All buckets of the workgroup's 2048 cells share ONE 64-bit
+  // atomic (buckets in the low word, tasks in the high one: C_NBIG, C_NTASKS), in flight during the look-back: in the
+  // pile-up regime nearly every wave has such a bucket, and an atomic per wave on that one address (11 ns each) was 6 us.
+  // (The tasks used to be laid out by the last workgroup, alone on the GPU: 8 of the scan's 17 us there.)
+  const bool wave_has_big = __ballot(my_big > 0) != 0;
+  const int incl_t = wave_has_big ? wave_scan_add(my_tasks) : 0, wave_big = wave_has_big ? wave_scan_add(my_big) : 0;  // lane 63: the wave's
+  const int incl = wave_scan_add(sum);
+  if (lane == 63) {
+    waveTot[wv] = incl;
+    waveTasks[wv] = incl_t;
+    waveBig[wv] = wave_big;
+  }
+  __syncthreads();
+  int wbase = 0, tot = 0, tbase = 0, all_tasks = 0, all_big = 0;
+  for (int k = 0; k < kBlock / 64; ++k) {
+    if (k < wv) {
+      wbase += waveTot[k];
+      tbase += waveTasks[k];
+    }
+    tot += waveTot[k];
+    all_tasks += waveTasks[k];
+    all_big += waveBig[k];
+  }
+  const int excl = wbase + incl - sum;
+  if (wv == 0) {  // the look-back is one wave's work
+    unsigned long long got = 0;
+    if (all_big > 0 && lane == 0)
+      got = __hip_atomic_fetch_add((unsigned long long*)&counters[C_NBIG], (unsigned long long)all_big | ((unsigned long long)all_tasks << 32),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int prefix = 0;
+    if (blk == 0) {
+      if (lane == 0) __hip_atomic_store(&desc[0], scan_desc(stamp, kDescPrefix, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (lane == 0) __hip_atomic_store(&desc[blk], scan_desc(stamp, kDescTotal, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int j = blk - 1;; j -= 64) {  // wave-uniform: 64 predecessors per step, nearest first
+        const int idx = j - lane;
+        unsigned long long d = scan_desc(stamp, kDescPrefix, 0);  // before block 0: nothing, and known
+        int polls = 0;
+        bool late;
+        do {
+          if (idx >= 0) d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          late = (unsigned)(d >> 34) != stamp;
+          if (__ballot(late) == 0) break;
+          __builtin_amdgcn_s_sleep(2);
+        } while (++polls < kScanMaxPolls);
+        if (__ballot(late)) {  // never seen: a predecessor that was not started -- give up loudly instead of hanging
+          if (lane == 0) atomicOr(&counters[C_FLAGS], F_SCAN_TIMEOUT);
+          break;
+        }
+        const unsigned long long known = __ballot(((unsigned)(d >> 32) & 3u) == kDescPrefix);
+        const int stop = known ? __ffsll(known) - 1 : 63;  // the nearest predecessor that knows its prefix ends the walk
+        prefix += wave_sum(lane <= stop ? (int)(unsigned)d : 0);
+        if (known) break;
+      }
+      if (lane == 0) __hip_atomic_store(&desc[blk], scan_desc(stamp, kDescPrefix, prefix + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) {
+      blockBase = prefix;
+      taskBase = (int)(got >> 32);
+    }
+  }
+  __syncthreads();
+  const int start0 = blockBase + excl;
+#pragma unroll
+  for (int k = 0; k < kScanPerThread; ++k)
+    if (base + k <= n) out[base + k] = start0 + v[k];  // index n: one-past-the-end entry
+  if (my_big > 0) {
+    int first = taskBase + tbase + incl_t - my_tasks;
 #pragma unroll
     for (int k = 0; k < kScanPerThread; ++k) {
-      int e = base + k < n ? in[base + k] : 0;
-      v[k] = sum;
-      sum += e;
-      // rare: a bucket worth sorting properly is cut into k_sort_big's tasks right here -- one task per chunk of kSortChunk
-      // slots, listed in whatever order the atomics hand out (the tasks are independent).  The wave's buckets share one
-      // 64-bit atomic (buckets in the low word, tasks in the high one: C_NBIG, C_NTASKS).  (The tasks used to be laid out
-      // by the last workgroup, alone on the GPU: 8 of the scan's 17 us in the pile-up regime.)
-      const bool bigc = e > kSortThreshold;
-      if (__ballot(bigc)) {
-        const int nt = bigc ? (e + kSortChunk - 1) / kSortChunk : 0;
-        const int incl_t = wave_scan_add(nt);
-        const unsigned long long m = __ballot(bigc);
-        const int total_t = __builtin_amdgcn_readlane(incl_t, 63);
-        unsigned long long got = 0;
-        if (lane == 0)
-          got = __hip_atomic_fetch_add((unsigned long long*)&counters[C_NBIG], (unsigned long long)__popcll(m) | ((unsigned long long)total_t << 32),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int first = __builtin_amdgcn_readfirstlane((int)(got >> 32)) + incl_t - nt;
+      const int e = (k + 1 < kScanPerThread ? v[k + 1] : sum) - v[k];
+      if (e > kSortThreshold) {
+        const int nt = (e + kSortChunk - 1) / kSortChunk;
         const bool fits = first + nt <= kMaxSortTasks;
         for (int j = 0; j < nt && first + j < kMaxSortTasks; ++j)  // a bucket cut off by the list's end: no-op tasks, ranked in K4
           sortTasks[first + j] = make_int2(fits ? base + k : -1, j | ((min(kSortChunk, e - j * kSortChunk) - 1) << 20));
+        first += nt;
       }
     }
-    const int incl = wave_scan_add(sum);
-    if (lane == 63) waveTot[wv] = incl;
-    __syncthreads();
-    int wbase = 0;
-    for (int k = 0; k < wv; ++k) wbase += waveTot[k];
-    int excl = wbase + incl - sum;
-#pragma unroll
-    for (int k = 0; k < kScanPerThread; ++k)
-      if (base + k <= n) out[base + k] = excl + v[k];  // index n: one-past-the-end entry
-    if (threadIdx.x == kBlock - 1)
-      __hip_atomic_store(&blockSums[blockIdx.x], excl + sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // ticket: what the last workgroup reads of the others -- the block totals and the list of big buckets, nothing
-  // else -- is stored at agent scope (past the XCD's L2) and has arrived before the ticket is drawn: every thread waits
-  // for its own stores, then the barrier, then the ticket.  A release fence here instead writes the XCD's whole L2
-  // back, once per workgroup, under a running kernel: 3 of 13 us at 1,048,576 particles, 16 of 35 at 4,194,304.
-  // The bucket starts (`out`) are plain stores: the kernels that follow read them, the last workgroup does not.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0)
-    last = __hip_atomic_fetch_add(&counters[C_TICKET], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
-  __syncthreads();
-  if (!last) return;
-  __threadfence();  // acquire: nothing stale in this CU's caches
-  const int nb = gridDim.x;
-  int carry = 0;
-  // kSumsPerThread consecutive block totals per thread and pass, their loads issued together: 2048 totals (4 M cells)
-  // in one pass of load -> scan -> store instead of one pass per 256 -- this tail runs alone on the GPU
-  constexpr int kSumsPerThread = 8;
-  for (int b0 = 0; b0 < nb; b0 += kBlock * kSumsPerThread) {
-    const int k0 = b0 + threadIdx.x * kSumsPerThread;
-    int e[kSumsPerThread];
-#pragma unroll
-    for (int j = 0; j < kSumsPerThread; ++j)
-      e[j] = k0 + j < nb ? __hip_atomic_load(&blockSums[k0 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    int mine = 0;
-#pragma unroll
-    for (int j = 0; j < kSumsPerThread; ++j) mine += e[j];
-    const int incl = wave_scan_add(mine);
-    __syncthreads();
-    if (lane == 63) waveTot[wv] = incl;
-    __syncthreads();
-    int wbase = 0, tot = 0;
-    for (int q = 0; q < kBlock / 64; ++q) {
-      if (q < wv) wbase += waveTot[q];
-      tot += waveTot[q];
-    }
-    int excl = carry + wbase + incl - mine;
-#pragma unroll
-    for (int j = 0; j < kSumsPerThread; ++j) {
-      if (k0 + j < nb) blockOff[k0 + j] = excl;
-      excl += e[j];
-    }
-    carry += tot;
-  }
-  const int nbig_all = __hip_atomic_load(&counters[C_NBIG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (threadIdx.x == 0) {
-    counters[C_NT] = carry;  // live particles = entries of the sorted arrays
-    counters[C_TICKET] = 0;
-    // a hint for the host, in host-mapped memory: were there big buckets?  It is read without any
-    // synchronisation when the NEXT tick is enqueued and only decides whether k_sort_big is launched.
-    bigHint[0] = nbig_all;
-  }
+  if (blk == (int)gridDim.x - 1 && threadIdx.x == 0) counters[C_NT] = blockBase + tot;  // live particles = entries of the sorted arrays
 }
 
 // ------------------------------------------------------------------------------------------
@@ -732,8 +741,11 @@ __global__ void __launch_bounds__(kReorderBlock)
               const double* __restrict__ vyS, XY* __restrict__ xyT, XY* __restrict__ vvT, int* __restrict__ idT,
               int* __restrict__ cellT,
               int* __restrict__ wslotT, const int* __restrict__ sortedStamp, int stamp, int ncols,
-              int* __restrict__ tileBounds, int live_hint) {
+              int* __restrict__ tileBounds, int live_hint, volatile int* __restrict__ bigHint) {
   SC_TIMELINE_KERNEL(4);
+  // a hint for the host, in host-mapped memory: were there big buckets?  It is read without any synchronisation when a
+  // later tick is enqueued and only decides whether k_sort_big and the grouping kernel variants are launched
+  if (blockIdx.x == 0 && threadIdx.x == 0) bigHint[0] = counters[C_NBIG];
   __shared__ SortKey ck[kRankChunk];
   __shared__ int wcell[kReorderBlock + 2 * kRankWindow];
   __shared__ int pick;

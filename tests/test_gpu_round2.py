@@ -520,3 +520,24 @@ def test_resume_after_the_fallback_to_the_host_stream(sc, tmp_path):
     run(c, 12)
     for x, y in zip(c.engine.download(), want):
         assert np.array_equal(x, y)
+
+
+# ------------------------------------------------------------------ the bucket scan on its own (round 3)
+def test_bucket_scan_and_task_list_over_many_workgroups(tmp_path):
+    """k_scan_cells by itself (scripts/scan_check.hip, compiled here): bucket starts == a host prefix sum and the list
+    of k_sort_big's tasks == one task per 1024 slots of every bucket above 96, for 1 .. 2442 workgroups with no, a few
+    and thousands of such buckets -- the parity tests' worlds have a handful of scan workgroups, the contract workload
+    140, and a wrong task list (round 3: a wave total read from the wrong lane) shows only with many."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = tmp_path / "scan_check"
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-w", f"-I{root / 'include'}",
+                    f"-I{root / 'sand_crate_amd' / 'csrc'}", str(root / "scripts" / "scan_check.hip"), "-o", str(exe)],
+                   check=True, timeout=300)
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    lines = [ln for ln in res.stdout.splitlines() if "cells," in ln]
+    assert len(lines) == 12 and all("starts ok, tasks ok" in ln for ln in lines), res.stdout
