@@ -819,7 +819,7 @@ int sc_step_begin(sc_ctx* c) {
   // hint in host-mapped memory): rank this tick's big buckets over the whole GPU first
   if (piles_expected(c)) {
     Bracket br(c, K_SCAN);
-    hipLaunchKernelGGL(k_sort_big, dim3(4 * c->num_cus), dim3(kSortBlock), 0, c->stream, c->counters, c->sortTasks,
+    hipLaunchKernelGGL(k_sort_big, dim3(kSortGridPerCu * c->num_cus), dim3(kSortBlock), 0, c->stream, c->counters, c->sortTasks,
                        Buckets{c->cellStart}, c->keys, c->sortedStamp, stamp);
   }
   {

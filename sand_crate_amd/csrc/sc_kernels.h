@@ -304,13 +304,21 @@ __global__ void __launch_bounds__(kBlock) k_scan_fix(int* __restrict__ out, int 
 // only, which the dispatcher starts first; the wait is bounded all the same (F_SCAN_TIMEOUT).
 constexpr int kSortThreshold = 96;  // buckets above this many particles are listed for k_sort_big
 #ifndef SC_SORT_BLOCK
-#define SC_SORT_BLOCK 256
+#define SC_SORT_BLOCK 512
+#define SC_SORT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
-constexpr int kSortBlock = SC_SORT_BLOCK;  // threads of a sorting task
+constexpr int kSortBlock = SC_SORT_BLOCK;
+#ifndef SC_SORT_WAVES_ATTR
+#define SC_SORT_WAVES_ATTR
+#endif  // threads of a sorting task
 #ifndef SC_SORT_CHUNK
 #define SC_SORT_CHUNK 1024
 #endif
 constexpr int kSortChunk = SC_SORT_CHUNK;  // slots per sorting task (12 B of LDS per slot for the keys)
+#ifndef SC_SORT_GRID_PER_CU
+#define SC_SORT_GRID_PER_CU 4
+#endif
+constexpr int kSortGridPerCu = SC_SORT_GRID_PER_CU;  // k_sort_big's workgroups per CU (each takes every grid-th task)
 constexpr int kSortBins = 256;         // bins of a chunk (by sampled splitters)
 #ifndef SC_MAX_SORT_TASKS
 #define SC_MAX_SORT_TASKS 16384
@@ -465,7 +473,7 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
 
 __device__ __forceinline__ bool key_less(double xa, int ia, double xb, int ib) { return xa < xb || (xa == xb && ia < ib); }
 
-__global__ void __launch_bounds__(kSortBlock)
+__global__ void __launch_bounds__(kSortBlock) SC_SORT_WAVES_ATTR
     k_sort_big(const int* __restrict__ counters, const int2* __restrict__ sortTasks,
                Buckets bk, SortKey* __restrict__ keys, int* __restrict__ sortedStamp, int stamp) {
   SC_TIMELINE_KERNEL(5);
