@@ -27,8 +27,11 @@ def show(k, title, cols, names):
     dt = np.diff(sel, axis=1)
     life = sel[:, -1] - sel[:, 0]
     print(f"{title}: {ok.sum()} waves with every stamp, wave life median {np.median(life):.0f} mean {life.mean():.0f} p95 {np.percentile(life, 95):.0f} cycles")
+    slow = life >= np.percentile(life, 99)  # the waves the kernel ends with
     for j, label in enumerate(names):
-        print(f"    {label:44s} median {np.median(dt[:, j]):8.0f}   mean {dt[:, j].mean():8.0f}   p95 {np.percentile(dt[:, j], 95):8.0f}   p99 {np.percentile(dt[:, j], 99):8.0f}")
+        print(f"    {label:44s} median {np.median(dt[:, j]):8.0f}   mean {dt[:, j].mean():8.0f}   p95 {np.percentile(dt[:, j], 95):8.0f}   p99 {np.percentile(dt[:, j], 99):8.0f}   slowest 1 % of waves: mean {dt[slow, j].mean():8.0f}")
+    idx = np.flatnonzero(ok)[slow]
+    print(f"    the slowest 1 % of waves: mean life {life[slow].mean():.0f} cycles; their wave numbers (of {waves}): " + " ".join(str(i) for i in idx[:: max(1, len(idx) // 24)]))
 # a wave of the scatter that is not scrambled never takes stamp 2: report the two kinds apart
 st = buf[4, :waves]
 scr = st[:, 2] > st[:, 1]

@@ -400,6 +400,32 @@ def test_pile_up_buckets_sort_and_rank(sc):
     assert np.array_equal(table, ref_table)
 
 
+def test_buckets_of_many_sorted_chunks_rank_together(sc):
+    """Buckets of 6 and more sorted chunks (k_sort_big sorts 1024 slots at a time) are ranked by the wave together
+    (k_reorder: the first and the last lane's bounds in every other chunk, the keys between them through LDS): 7 chunks,
+    36 chunks (two passes of 32), exact ties in x, near-ties that spread two chunks differently, and buckets whose
+    starts make the waves straddle chunks and buckets.  The order must be the reference's (row, x, id)."""
+    from oracle.neighbors import strip_sort
+    rs = np.random.RandomState(5)
+    d = 0.05
+    def cell(col, row):
+        return np.array([col * d, row * d])
+    parts = [
+        cell(3, 4) + np.column_stack((np.round(rs.rand(7013) * 40) / 40 * d * 0.9, rs.rand(7013) * d * 0.99)),   # 41 x values: ties
+        cell(4, 4) + rs.rand(37, 2) * d * 0.99,                                                                   # its neighbor: small
+        cell(5, 4) + np.column_stack((rs.rand(36100) ** 3 * d * 0.99, rs.rand(36100) * d * 0.99)),                # 36 chunks, skewed in x
+        cell(6, 4) + np.column_stack((np.full(6500, 0.0321 * d), rs.rand(6500) * d * 0.99)),                      # one x: ranked by id alone
+        cell(9, 9) + np.column_stack((np.where(rs.rand(9000) < 0.5, 0.1, 0.9) * d + rs.rand(9000) * 1e-12, rs.rand(9000) * d * 0.99)),
+        rs.rand(4000, 2) * 0.9 + 0.02,
+    ]
+    pts = np.vstack(parts)
+    pts = pts[rs.permutation(len(pts))]
+    rows, order, counts, table = sc.neighbor_search(pts, d)
+    ref_rows, ref_order = strip_sort(pts, d)
+    assert np.array_equal(order, ref_order)
+    assert np.array_equal(rows, ref_rows)
+
+
 @pytest.mark.parametrize("seed,tile", [(11, "narrow"), (12, "wide")])
 def test_dense_regions_windowed_search(sc, seed, tile, monkeypatch):
     """Tiles too large for LDS are searched through a sliding window; every kind of scan must keep the
