@@ -647,8 +647,8 @@ __global__ void __launch_bounds__(kSortBlock) SC_SORT_WAVES_ATTR
 // ------------------------------------------------------------------------------------------
 // K3  scatter: a slot inside the particle's cell bucket, in arrival order.  The returning
 // atomic counts the bucket back down to zero, so cellCount needs no clearing for the next tick.
-// The bucket slot receives the sort key (x) and the particle's storage index, so that K4 ranks
-// over CONTIGUOUS keys instead of chasing perm -> x.
+// The bucket slot receives the sort key and the particle's storage index (one SortKey record) and the packed cell,
+// so that K4 ranks over CONTIGUOUS keys instead of chasing storage index -> x.
 // ------------------------------------------------------------------------------------------
 // XCD-aware block -> chunk mapping (same idea as sc_tiled.h: tile_of_block): workgroups are dealt round-robin over
 // the 8 XCDs, so giving every XCD one contiguous run of chunks keeps neighboring chunks -- whose gathers and
