@@ -335,6 +335,14 @@ int build_world(sc_ctx* c, World& w, const sc_params& p, int nseg, const Seg* se
     w.ncols = (int)(ccmax - ccmin + 1) + 2;
   }
   w.inv_d = 1.0 / w.d;
+  // With dx = fl(x_j - x_i), |dx| < d (1 - 2^-20) puts the true difference below d (1 - 2^-21); fl(x +- d) is off by at most
+  // |x +- d| 2^-53 <= d 2^-21 as long as |x| / d < 2^32: then x_j is inside [fl(x_i - d), fl(x_i + d)] and x_i inside
+  // [fl(x_j - d), fl(x_j + d)] -- both forms of the reference's window (collision_detector.py:106-119, :85-88) hold.
+  {
+    const long long far = std::max(std::llabs(w.col0), std::llabs(w.col0 + w.ncols)) + 2;
+    const long long far_r = std::max(std::llabs(w.row0), std::llabs(w.row0 + w.nrows)) + 2;
+    w.dsafe = std::max(far, far_r) < (1LL << 30) ? w.d * (1.0 - 0x1p-20) : 0.0;
+  }
   w.row0d = (double)w.row0;
   w.col0d = (double)w.col0;
   w.eta_scale = (w.d * w.level) * (1.0 / 4294967296.0);

@@ -47,6 +47,8 @@ struct World {
   double dt_gx, dt_gy, dt_visc, dt_pamp;
   // decision thresholds derived on the host, see sc_host.cpp: make_world()
   double t_nbr;      // largest s with sqrt(s) <= d          (collision_detector.py:78-79)
+  double dsafe;      // |dx| below this and within the distance: inside the reference's x-window whatever the rounding of
+                     // x +- d (d (1 - 2^-20) when every |x| / d is below 2^30, else 0: the window expression always decides)
   double t_wall;     // largest s with sqrt(s) <= r * 1.2    (crate.py:229)
   double lo, hi;     // -r, 1 + r                             (crate.py:152)
   double touch_box;  // bounding-box reject radius for wall contact

@@ -175,12 +175,23 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
             XY q[kBatch];
 #pragma unroll
             for (int k = 0; k < kBatch; ++k) q[k] = txy[first + (v + k) * step];
+            // A candidate within the distance is inside the reference's window unless its |dx| is within 2^-20 d of d (then
+            // the rounding of x +- d could decide otherwise: World::dsafe, sandcrate_hip.hip) -- the window expression
+            // itself (two additions and two compares per candidate in the backward scans) is evaluated only for a batch
+            // in which some lane has such a hit: exact ties at distance d, i.e. tests, not fluids.
             unsigned inc[kBatch];
+            bool edge = false;
 #pragma unroll
             for (int k = 0; k < kBatch; ++k) {
               const double dx = q[k].x - xi, dy = q[k].y - yi;
-              const bool hit = (dx * dx + dy * dy <= w.t_nbr) & (window(q[k].x, xi) == 2) & (v + k < count);
-              inc[k] = hit ? kRow : 0u;
+              const bool near = (dx * dx + dy * dy <= w.t_nbr) & (v + k < count);
+              edge |= near & !(fabs(dx) < w.dsafe);
+              inc[k] = near ? kRow : 0u;
+            }
+            if (__ballot(edge)) {
+#pragma unroll
+              for (int k = 0; k < kBatch; ++k)
+                if (window(q[k].x, xi) != 2) inc[k] = 0u;
             }
             const double dxl = q[kBatch - 1].x - xi;
             const bool stop = step > 0 ? dxl > dstop : dxl < -dstop;
@@ -251,11 +262,18 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
 #pragma unroll
                 for (int k = 0; k < kWinBatch; ++k) q[k] = txy[base + (v + k) * step];
                 unsigned inc[kWinBatch];
+                bool edge = false;  // (as in the LDS scan: the window expression only for a batch with a hit at the window's edge)
 #pragma unroll
                 for (int k = 0; k < kWinBatch; ++k) {
                   const double dx = q[k].x - xi, dy = q[k].y - yi;
-                  const bool hit = (dx * dx + dy * dy <= w.t_nbr) & (window(q[k].x, xi) == 2) & (v + k < cnt);
-                  inc[k] = hit ? kRow : 0u;
+                  const bool near = (dx * dx + dy * dy <= w.t_nbr) & (v + k < cnt);
+                  edge |= near & !(fabs(dx) < w.dsafe);
+                  inc[k] = near ? kRow : 0u;
+                }
+                if (__ballot(edge)) {
+#pragma unroll
+                  for (int k = 0; k < kWinBatch; ++k)
+                    if (window(q[k].x, xi) != 2) inc[k] = 0u;
                 }
                 const double dxl = q[kWinBatch - 1].x - xi;
                 const bool stop = step > 0 ? dxl > dstop : dxl < -dstop;

@@ -400,6 +400,33 @@ def test_pile_up_buckets_sort_and_rank(sc):
     assert np.array_equal(table, ref_table)
 
 
+@pytest.mark.parametrize("origin", [0.0, 3.0, 1000.0])
+def test_pairs_at_the_edge_of_the_window(sc, origin):
+    """Pairs whose |dx| is within rounding of d -- a lattice of spacing d, the same with the spacing one ulp and 1e-7 d
+    off either way, rows of such lattices at dy = 0 and just above -- are decided by the reference's window
+    expressions x_i +- d / x_j +- d (collision_detector.py:85-88, :106-119) AND its distance predicate.  Pass A
+    evaluates the window expression only for a batch with a hit that close to the edge (World::dsafe): here nearly
+    every hit is one.  Small and large coordinates (the rounding of x +- d grows with |x|): lists == oracle."""
+    from oracle.neighbors import neighbor_lists, strip_sort
+    d = 0.05
+    rows = []
+    for r, (step, dy) in enumerate([(d, 0.0), (np.nextafter(d, 1.0), 0.0), (np.nextafter(d, 0.0), 0.0), (d * (1 + 1e-7), 0.0),
+                                     (d * (1 - 1e-7), 0.0), (d, 1e-9), (d * (1 - 1e-12), 3e-8), (d, d * 1e-4)]):
+        k = np.arange(90)
+        x = origin + 0.013 + k * step
+        y = origin + 0.017 + 3 * r * d + np.where(k % 2 == 0, 0.0, dy)
+        rows.append(np.column_stack((x, y)))
+    rs = np.random.RandomState(int(origin) + 1)
+    pts = np.vstack(rows + [origin + rs.rand(3000, 2) * 4.0])
+    pts = pts[rs.permutation(len(pts))]
+    rows_, order, counts, table = sc.neighbor_search(pts, d)
+    ref_rows, ref_order = strip_sort(pts, d)
+    assert np.array_equal(order, ref_order)
+    ref_counts, ref_table = neighbor_lists(pts, d)
+    assert np.array_equal(counts, ref_counts)
+    assert np.array_equal(table, ref_table)
+
+
 def test_buckets_of_many_sorted_chunks_rank_together(sc):
     """Buckets of 6 and more sorted chunks (k_sort_big sorts 1024 slots at a time) are ranked by the wave together
     (k_reorder: the first and the last lane's bounds in every other chunk, the keys between them through LDS): 7 chunks,
