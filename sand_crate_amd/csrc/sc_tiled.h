@@ -153,8 +153,8 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       constexpr int kHalf = CAP / 2, kSerial = 32;
       WindowProbe probe;  // (diagnostic builds only: sc_diag.h)
       const double dstop = w.d * (1.0 + 0x1p-20);
-      // next free entry of this thread's list (LDS tiles) as a byte offset into `list`; row kMaxNbr is a spare one that
-      // takes the writes of a full list, so that an append is a store and a clamped add -- no branch
+      // next free entry of this thread's list (LDS tiles) as a byte offset into `list`; the rows from kMaxNbr on are spare
+      // ones that take the writes of a full list, so that an append is a store and an add -- no branch, one clamp per batch
       constexpr unsigned kRow = (kTileW + 2) * sizeof(unsigned short);
       char* const lbase = (char*)&list[0][0];
       const unsigned lo0 = t * (unsigned)sizeof(unsigned short), lend = kMaxNbr * kRow + lo0;
@@ -196,10 +196,11 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
             const double dxl = q[kBatch - 1].x - xi;
             const bool stop = step > 0 ? dxl > dstop : dxl < -dstop;
 #pragma unroll
-            for (int k = 0; k < kBatch; ++k) {  // trim (:91-93): a full list writes its spare row
+            for (int k = 0; k < kBatch; ++k) {  // trim (:91-93): a full list writes its spare rows
               *(unsigned short*)(lbase + lo) = (unsigned short)(first + (v + k) * step);
-              lo = min(lo + inc[k], lend);
+              lo += inc[k];
             }
+            lo = min(lo, lend);  // once per batch: a list that fills up inside a batch runs into the kBatch spare rows
             done = stop | (lo == lend);
           }
         } else {
@@ -278,10 +279,11 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
                 const double dxl = q[kWinBatch - 1].x - xi;
                 const bool stop = step > 0 ? dxl > dstop : dxl < -dstop;
 #pragma unroll
-                for (int k = 0; k < kWinBatch; ++k) {  // trim (:91-93): a full list writes its spare row
+                for (int k = 0; k < kWinBatch; ++k) {  // trim (:91-93): a full list writes its spare rows
                   *(unsigned short*)(lbase + lw) = (unsigned short)(pos + (v + k) * step);
-                  lw = min(lw + inc[k], lend);
+                  lw += inc[k];
                 }
+                lw = min(lw, lend);
                 stopped = stop | (lw == lend);
               }
               const int walked = min(v, cnt);
@@ -638,7 +640,7 @@ __global__ void __launch_bounds__(kTileW)
   constexpr int kPad = SC_SCAN_BATCH - 1;  // a batched scan may read this far past either end of the tile
   __shared__ XY txy_padded[CAP + 2 * kPad];
   XY* const txy = txy_padded + kPad;
-  __shared__ unsigned short list[kMaxNbr + 1][kTileW + 2];  // tile slots of the neighbors, [slot][thread]; + a spare row (scan)
+  __shared__ unsigned short list[kMaxNbr + SC_SCAN_BATCH][kTileW + 2];  // tile slots of the neighbors, [slot][thread]; + spare rows (scan)
   __shared__ int wkey[6 * (kTileW / 64)];  // the windowed scans' round keys (2 per wave); the lists' reach per range (6 per wave)
 
   const int t = threadIdx.x;
