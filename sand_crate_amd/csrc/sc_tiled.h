@@ -67,14 +67,15 @@ __device__ __host__ __forceinline__ int tile_index(const Tile& t, int slot) {  /
 // A neighbor-table entry is a tile slot (>= 0) or, for a tile too large for u16 slots, -(index+1).
 __device__ __host__ __forceinline__ int entry_index(const Tile& t, int e) { return e >= 0 ? tile_index(t, e) : -e - 1; }
 
-// 1/sqrt(s) to about 2 ulp (explicit fma: no decision is taken on it; the forces it enters are float-tolerance math).  s = 0 gives NaN downstream, like the reference's 0/0 (crate.py:174).
+// 1/sqrt(s) to ~4e-15 relative (explicit fma: no decision is taken on it; the forces it enters are float-tolerance math,
+// contract 1e-5, tests 1e-9).  s = 0 gives NaN downstream, like the reference's 0/0 (crate.py:174).
 __device__ __forceinline__ double rsqrt_nr(double s) {
-  // v_rsq_f64 is good to ~2^-24 (measured 5e-8); one third-order step, y (1 + e/2 + 3e^2/8) with
-  // e = 1 - s y^2, brings it to ~2e-16 in five fp64 operations
+  // v_rsq_f64 is good to ~2^-24 (measured 5e-8); one Newton step, y (1 + e/2) with e = 1 - s y^2 (|e| <= 1e-7), leaves
+  // 3/8 e^2 = 4e-15 in four fp64 operations (the third-order step y (1 + e/2 + 3e^2/8) reached 2e-16 in five: one
+  // instruction per pair and pass more, 0.7 % of the tick, for digits nothing downstream resolves)
   const double y = __builtin_amdgcn_rsq(s);
   const double e = fma(-(s * y), y, 1.0);
-  const double p = fma(e, 0.375, 0.5);
-  return fma(y * e, p, y);
+  return fma(y * 0.5, e, y);
 }
 
 
