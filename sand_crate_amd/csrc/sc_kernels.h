@@ -758,6 +758,10 @@ constexpr int kRankChunk = 256;   // keys streamed through LDS per step (3 KB pe
 constexpr int kReorderBlock = 64; // one wave per workgroup: a big bucket is shared by 4x more CUs
 
 constexpr int kRankWindow = 12;   // slots either side of a particle in which a small bucket's ends are looked for
+#ifndef SC_RANK_SIDE
+#define SC_RANK_SIDE 4
+#endif
+constexpr int kRankSide = SC_RANK_SIDE;  // searches of a sorted bucket's other chunks that advance together (2: the same; 8: registers, 53 us)
 
 __global__ void __launch_bounds__(kReorderBlock)
     k_reorder(const int* __restrict__ counters, const SortKey* __restrict__ keys, const int* __restrict__ keyCell, const int* __restrict__ cellS, Buckets bk,
@@ -857,10 +861,7 @@ __global__ void __launch_bounds__(kReorderBlock)
     // the searches of up to four other chunks advance together, key and id of a probe requested at once: a step is ONE
     // round trip whatever the number of chunks and of exact ties in x (one chunk after the other, the id fetched only on a
     // tie -- the rule in a pile stopped on a wall -- a bucket of 4000 was a chain of 60 round trips: the kernel's tail)
-#ifndef SC_RANK_SIDE
-#define SC_RANK_SIDE 4
-#endif
-    constexpr int kSide = SC_RANK_SIDE;
+    constexpr int kSide = kRankSide;
     for (int r0 = 0; r0 < nch; r0 += kSide) {
       int lo[kSide], hi[kSide];
 #pragma unroll
