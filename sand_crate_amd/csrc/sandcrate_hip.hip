@@ -127,8 +127,7 @@ struct sc_ctx {
   int64_t cellAlloc = 0;
   double* wrec[2] = {nullptr, nullptr};  // wall records of even / odd ticks
   int* nbr = nullptr;              // neighbor table of tiles beyond 65535 entries: -(sorted index + 1), 32 bit
-  unsigned short* nbr16 = nullptr;  // neighbor table, slot-major: tile slots, 16 bit
-  unsigned char* cnt = nullptr;
+  NbrRow* rows = nullptr;  // neighbor table: a 48-byte row per sorted particle (twenty 16-bit tile slots and the count)
   double* P = nullptr;
   XY *sxy = nullptr, *svv = nullptr, *snn = nullptr;  // the sorted positions and velocities, the surface normals: 16-byte pairs
   int* counters = nullptr;
@@ -483,7 +482,7 @@ template <int NOISE, bool ENUM, bool DENS, int CAP>
 void launch_pass_a_cap(sc_ctx* c) {
   auto launch = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, dim3(tile_grid(c)), dim3(kTileW), 0, c->stream, c->w, c->counters,
-                       c->sxy, c->id[1], c->cellT, Buckets{c->cellStart}, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta, c->offById,
+                       c->sxy, c->id[1], c->cellT, Buckets{c->cellStart}, c->nbr, c->rows, (int)c->cap, c->eta, c->offById,
                        c->P, c->snn, ENUM ? c->tileBounds : c->tileBoundsT, c->tileBand, c->tileBoundsT);
   };
   if (ENUM && DENS && piles_expected(c))  // dense tiles ahead: the instantiation that stages their lists' reach
@@ -528,7 +527,7 @@ void launch_pass_b(sc_ctx* c, const WallInputs& wn, int part = 0) {
   hipStream_t stream = c->stream;
   auto launch = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kTileW), 0, stream, c->w, c->counters, c->sxy, c->svv,
-                       c->id[1], c->wslotT, c->cellT, c->nbr, c->nbr16, c->cnt, (int)c->cap, c->eta, c->offById, c->P,
+                       c->id[1], c->wslotT, c->cellT, c->nbr, c->rows, (int)c->cap, c->eta, c->offById, c->P,
                        c->snn, c->wrec[cur], c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], c->tileBoundsT,
                        c->bigHintDev, wn, c->cellS, c->wslotS, c->cellCount, c->wrec[nxt], c->haloL, c->haloR, c->haloCap,
                        c->monitor, c->tileBand, part, bandw, c->band_epoch);
@@ -625,8 +624,7 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
   if (e == hipSuccess) e = dalloc(&c->wrec[0], 5 * n);
   if (e == hipSuccess) e = dalloc(&c->wrec[1], 5 * n);
   if (e == hipSuccess) e = dalloc(&c->nbr, (size_t)kMaxNbr * n);
-  if (e == hipSuccess) e = dalloc(&c->nbr16, (size_t)kMaxNbr * n);
-  if (e == hipSuccess) e = dalloc(&c->cnt, n);
+  if (e == hipSuccess) e = dalloc(&c->rows, n);
   if (e == hipSuccess) e = dalloc(&c->P, n);
   if (e == hipSuccess) e = dalloc(&c->snn, n);
   if (e == hipSuccess) e = dalloc(&c->sxy, n);
@@ -657,7 +655,7 @@ int sc_destroy(sc_ctx* c) {
   if (c->ev_band) (void)hipEventDestroy(c->ev_band);
   if (c->ev_xchg) (void)hipEventDestroy(c->ev_xchg);
   void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->keys, c->keyCell, c->tileBounds, c->tileBoundsT, c->tileBand, c->cellCount, c->cellStart, c->scanDesc, c->sortedStamp, c->sortTasks, c->wrec[0], c->wrec[1],
-                  c->nbr, c->nbr16, c->cnt, c->P, c->snn, c->sxy, c->svv, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
+                  c->nbr, c->rows, c->P, c->snn, c->sxy, c->svv, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
                   c->stage_xy, c->stage_vxy, c->stage_ids, c->owned_out, c->colHist, c->rng, c->monitor,
                   c->snap_d[0], c->snap_d[1], c->snap_d[2], c->snap_d[3], c->snap_id_d, c->snap_rng_d};
   for (void* p : ptrs)
@@ -850,7 +848,7 @@ int sc_step_begin(sc_ctx* c) {
     if (rc) return rc;
     Bracket br(c, K_NOISE_OFFSETS);
     HIPCHK(hipMemsetAsync(c->cntById, 0, c->next_id * sizeof(int), c->stream));
-    hipLaunchKernelGGL(k_count_by_id, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->id[1], c->cnt, c->cntById);
+    hipLaunchKernelGGL(k_count_by_id, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->id[1], (const unsigned int*)c->rows, c->cntById);
     rc = launch_scan(c, c->cntById, c->offById, c->next_id, c->idBlockSums, nullptr);
     if (rc) return rc;
   }
@@ -864,7 +862,7 @@ int sc_step_begin(sc_ctx* c) {
 int sc_step_stats(sc_ctx* c, sc_stats* out) {
   if (!c || !out) return fail(SC_ERR_ARG, "null argument");
   if (!c->in_step) return fail(SC_ERR_STATE, "sc_step_stats needs sc_step_begin first");
-  hipLaunchKernelGGL(k_count_stats, dim3(1), dim3(kBlock), 0, c->stream, c->counters, c->cnt, c->wslotT);
+  hipLaunchKernelGGL(k_count_stats, dim3(1), dim3(kBlock), 0, c->stream, c->counters, (const unsigned int*)c->rows, c->wslotT);
   int h[C_COUNT];
   int rc = read_counters(c, h);
   if (rc) return rc;
@@ -1115,35 +1113,42 @@ int sc_download_neighbors(sc_ctx* c, int64_t* ids, int32_t* counts, int64_t* nei
   if (n_out) *n_out = n;
   if (n > room) return fail(SC_ERR_CAPACITY, "host arrays too small");
   std::vector<int> id(n);
-  std::vector<unsigned char> cnt(n);
+  std::vector<NbrRow> rows(n);
   std::vector<double> hxy(2 * n);
   std::vector<int> slot(n);
-  std::vector<unsigned short> slot16(n);
   const int64_t nblocks = (n + kTileW - 1) / kTileW;
   std::vector<int> tb(6 * std::max<int64_t>(nblocks, 1));
   if ((rc = fetch(c, tb.data(), c->tileBoundsT, 6 * nblocks * sizeof(int)))) return rc;
-  if ((rc = fetch(c, id.data(), c->id[1], n * sizeof(int))) || (rc = fetch(c, cnt.data(), c->cnt, n)) ||
+  if ((rc = fetch(c, id.data(), c->id[1], n * sizeof(int))) || (rc = fetch(c, rows.data(), c->rows, n * sizeof(NbrRow))) ||
       (rc = fetch(c, hxy.data(), c->sxy, 2 * n * sizeof(double))))
     return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
   if (neighbors)
     for (int64_t k = 0; k < n * kMaxNbr; ++k) neighbors[k] = -1;
+  auto tile_of = [&](int64_t k) {  // the table holds tile slots of the particle's block
+    const int* b = tb.data() + 6 * (k / kTileW);
+    return Tile{b[0], b[1] - b[0], b[2], b[3] - b[2], b[4], b[5] - b[4]};
+  };
+  bool any_big = false;  // a block whose tile exceeds 16-bit slots: the 32-bit table holds -(index + 1)
+  for (int64_t b = 0; b < nblocks; ++b) {
+    const Tile tl = tile_of(b * kTileW);
+    any_big |= tl.n0 + tl.n1 + tl.n2 > kSlotMax;
+  }
   for (int s = 0; s < kMaxNbr && neighbors; ++s) {
-    if ((rc = fetch(c, slot.data(), c->nbr + (size_t)s * c->cap, n * sizeof(int))) ||
-        (rc = fetch(c, slot16.data(), c->nbr16 + (size_t)s * c->cap, n * sizeof(unsigned short))))
-      return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (any_big) {
+      if ((rc = fetch(c, slot.data(), c->nbr + (size_t)s * c->cap, n * sizeof(int)))) return rc;
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
     for (int64_t k = 0; k < n; ++k) {
-      if (s >= cnt[k]) continue;
-      const int* b = tb.data() + 6 * (k / kTileW);  // the table holds tile slots of the particle's block
-      const Tile tl{b[0], b[1] - b[0], b[2], b[3] - b[2], b[4], b[5] - b[4]};
-      const bool big = tl.n0 + tl.n1 + tl.n2 > kSlotMax;  // then the 32-bit table holds -(index + 1)
-      neighbors[k * kMaxNbr + s] = id[entry_index(tl, big ? slot[k] : (int)slot16[k])];
+      if (s >= (int)rows[k].w[kRowCount]) continue;
+      const Tile tl = tile_of(k);
+      const bool big = tl.n0 + tl.n1 + tl.n2 > kSlotMax;
+      neighbors[k * kMaxNbr + s] = id[entry_index(tl, big ? slot[k] : row_entry(rows[k], s))];
     }
   }
   for (int64_t k = 0; k < n; ++k) {
     if (ids) ids[k] = id[k];
-    if (counts) counts[k] = cnt[k];
+    if (counts) counts[k] = (int32_t)rows[k].w[kRowCount];
     if (fixed_xy) {
       fixed_xy[2 * k] = hxy[2 * k];
       fixed_xy[2 * k + 1] = hxy[2 * k + 1];

@@ -973,16 +973,18 @@ __global__ void __launch_bounds__(kReorderBlock)
 
 // K5-K7 (neighbor search, pass A, pass B) are the LDS-tiled kernels of sc_tiled.h.
 
+constexpr int kRowWords = 12, kRowCount = 10;  // a neighbor-table row in 32-bit words, and the word that holds the count (NbrRow)
+
 // Sum and maximum of the neighbor counts, on demand (sc_step_stats).  Kept out of the search kernel:
 // one atomic per workgroup on a single address serialises at ~12 ns each and dominated it.
-__global__ void __launch_bounds__(kBlock) k_count_stats(int* __restrict__ counters, const unsigned char* __restrict__ cnt,
+__global__ void __launch_bounds__(kBlock) k_count_stats(int* __restrict__ counters, const unsigned int* __restrict__ rows,
                                                         const int* __restrict__ wslot) {
   __shared__ int ssum[kBlock / 64], smax[kBlock / 64], swall[kBlock / 64];
   int n = counters[C_NT];
   long long sum = 0;
   int mx = 0, walls = 0;
   for (int i = threadIdx.x; i < n; i += kBlock) {
-    int c = cnt[i];
+    int c = (int)rows[(size_t)i * kRowWords + kRowCount];  // (the count of particle i's table row: sc_tiled.h, NbrRow)
     sum += c;
     mx = max(mx, c);
     walls += wslot[i] >= 0;  // particles with a wall record (crate.py:229: V_i not empty)
@@ -1013,9 +1015,9 @@ __global__ void __launch_bounds__(kBlock) k_count_stats(int* __restrict__ counte
 // host-noise mode: exclusive scan of C_i in particle-id order gives each particle's offset into
 // the host's rand(sum C_i, 2) block (crate.py:165-170 draws particle by particle in index order).
 __global__ void k_count_by_id(const int* __restrict__ counters, const int* __restrict__ id,
-                              const unsigned char* __restrict__ cnt, int* __restrict__ cntById) {
+                              const unsigned int* __restrict__ rows, int* __restrict__ cntById) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < counters[C_NT]) cntById[id[i]] = cnt[i];
+  if (i < counters[C_NT]) cntById[id[i]] = (int)rows[(size_t)i * kRowWords + kRowCount];
 }
 
 // Collider offset eta_ij of crate.py:169 for slot `slot` of a particle.  `z` is the particle's

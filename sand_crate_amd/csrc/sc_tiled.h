@@ -51,6 +51,29 @@ constexpr int kTileCapB = SC_CAP_B;   // pass B tile: (x, y), (sx, sy), P of the
 constexpr int kDenseTile = kTileW * 43 / 10;  // 1100 entries for 256 particles (the usual tile has ~800)
 constexpr int kSlotMax = 65535;  // lists are staged as u16 tile slots in pass A
 
+// The neighbor table: one 48-byte row per sorted particle -- twenty entries of 16 bits (tile slots, below) and the count --
+// written by pass A in three 16-byte stores and read by pass B in three 16-byte loads.  (Rounds 1-3 kept it slot-major,
+// entry s of all particles contiguous, so that a wave's access to one entry was one coalesced request: twenty 2-byte loads
+// per particle in pass B and up to twenty 2-byte stores in pass A, plus a separate count array.)
+struct alignas(16) NbrRow {
+  unsigned int w[12];  // w[0..9]: entries 2k (low half) and 2k + 1 (high half); w[10]: the count; w[11]: unused
+};
+static_assert(sizeof(NbrRow) == 4 * kRowWords && kMaxNbr == 2 * kRowCount, "a row is twenty 16-bit entries, the count and padding");
+__device__ __host__ __forceinline__ int row_entry(const NbrRow& r, int s) { return (int)((r.w[s >> 1] >> (16 * (s & 1))) & 0xFFFFu); }
+
+// A thread's list while it is being built, in LDS: kMaxNbr entries of 16 bits and SC_SCAN_BATCH spare ones (the writes of a
+// full list, below), thread-major -- the row is then copied to the table as it is.  The stride is an odd number of
+// 32-bit words, so that the rows of consecutive lanes start in different banks.
+constexpr int kListWords = ((kMaxNbr + SC_SCAN_BATCH) / 2) | 1;
+constexpr int kListStride = 4 * kListWords;
+struct Lists {
+  char* base;
+  __device__ __forceinline__ unsigned short& operator()(int s, int t) const {
+    return *(unsigned short*)(base + t * kListStride + 2 * s);
+  }
+  __device__ __forceinline__ unsigned int& word(int k, int t) const { return *(unsigned int*)(base + t * kListStride + 4 * k); }
+};
+
 struct Tile {
   int a0, n0;  // same rows
   int a1, n1;  // next rows
@@ -110,12 +133,11 @@ __device__ __forceinline__ int tile_of_block_ends_first(int tiles) {
 // Phases 3-5 of pass A for one particle.  LDS: where the tile is (compile time, see the header).
 template <int NOISE, bool ENUM, bool DENS, bool LDS, int CAP, bool STAGE = false>
 __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, const int total, XY* txy,
-                                            unsigned short (*list)[kTileW + 2], int* wkey, const int t, const int i,
+                                            const Lists list, int* wkey, const int t, const int i,
                                             const bool live, const int idi, const int e0, const int b0, const int b1,
                                             const int e1, const int bm, const int em, const XY* __restrict__ sxy,
                                             int* __restrict__ nbr,
-                                            unsigned short* __restrict__ nbr16,
-                                            unsigned char* __restrict__ cnt, const int cap,
+                                            NbrRow* __restrict__ rows, const int cap,
                                             const double* __restrict__ eta, const int* __restrict__ offById,
                                             double* __restrict__ P, XY* __restrict__ snn,
                                             const int tile_id, int* __restrict__ tileBoundsT) {
@@ -154,11 +176,11 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       constexpr int kHalf = CAP / 2, kSerial = 32;
       WindowProbe probe;  // (diagnostic builds only: sc_diag.h)
       const double dstop = w.d * (1.0 + 0x1p-20);
-      // next free entry of this thread's list (LDS tiles) as a byte offset into `list`; the rows from kMaxNbr on are spare
+      // next free entry of this thread's list (LDS tiles) as a byte offset into `list`; the entries from kMaxNbr on are spare
       // ones that take the writes of a full list, so that an append is a store and an add -- no branch, one clamp per batch
-      constexpr unsigned kRow = (kTileW + 2) * sizeof(unsigned short);
-      char* const lbase = (char*)&list[0][0];
-      const unsigned lo0 = t * (unsigned)sizeof(unsigned short), lend = kMaxNbr * kRow + lo0;
+      constexpr unsigned kRow = sizeof(unsigned short);
+      char* const lbase = list.base;
+      const unsigned lo0 = t * (unsigned)kListStride, lend = kMaxNbr * kRow + lo0;
       unsigned lo = lo0;
       auto scan = [&](bool want, int first, int count, int step, auto window) {
         if constexpr (LDS) {
@@ -343,7 +365,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
                     const unsigned long long hitm = __ballot(hit && lane < nlive);
                     const int rank = taken + __popcll(hitm & ((1ull << lane) - 1ull));
                     if (hit && lane < nlive && rank < need)
-                      list[oC + rank][wave0 + owner] = (unsigned short)(opos + (done + c * 64 + lane) * step);
+                      list(oC + rank, wave0 + owner) = (unsigned short)(opos + (done + c * 64 + lane) * step);
                     taken = min(taken + (int)__popcll(hitm), need);
                     stopped = stopm != 0 || taken == need;
                   }
@@ -419,10 +441,13 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       }
     }
   } else if (live) {
-    // lists were built by an earlier launch: bring them in (coalesced, slot-major)
-    C = cnt[i];
-    if (slots_fit)
-      for (int s = 0; s < C; ++s) list[s][t] = nbr16[(size_t)s * cap + i];
+    // lists were built by an earlier launch: bring them in
+    const NbrRow row = rows[i];
+    C = (int)row.w[kRowCount];
+    if (slots_fit) {
+#pragma unroll
+      for (int k = 0; k < kMaxNbr / 2; ++k) list.word(k, t) = row.w[k];
+    }
   }
 
   if (diag::kNoSearch) C = 0;
@@ -470,7 +495,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
     int lo0 = live ? self : INT_MAX, hi0 = live ? self : -1, lo1 = INT_MAX, hi1 = -1, lo2 = INT_MAX, hi2 = -1;
     if (live)
       for (int s = 0; s < C; ++s) {
-        const int e = list[s][t];
+        const int e = list(s, t);
         if (e < sr1) {
           lo0 = min(lo0, e);
           hi0 = max(hi0, e);
@@ -505,8 +530,8 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
           staged = true;
           if (live)
             for (int s = 0; s < C; ++s) {
-              const int e = list[s][t];
-              list[s][t] = (unsigned short)(e - (e < sr1 ? sub[0] : e < sr2 ? sub[1] : sub[2]));
+              const int e = list(s, t);
+              list(s, t) = (unsigned short)(e - (e < sr1 ? sub[0] : e < sr2 ? sub[1] : sub[2]));
             }
           const Tile part{nb[0], nb[1] - nb[0], nb[2], nb[3] - nb[2], nb[4], nb[5] - nb[4]};
           for (int slot = t; slot < mt; slot += kTileW) {
@@ -537,7 +562,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
     const int Cloop = diag::pairs_a(C);
     if (STAGE && !LDS && staged) {  // the neighbors are in the staged reach: an LDS tile's loop
       for (int s = 0; s < Cloop; ++s) {
-        const XY q = txy[list[s][t]];
+        const XY q = txy[list(s, t)];
         double rx, ry;
         pair_offset<NOISE>(w, z, s, eta, off, ox - q.x, oy - q.y, rx, ry);
         z += kGold;
@@ -556,7 +581,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
         for (int k = 0; k < kFetch; ++k) {
           const int sk = s + k;
           if (slots_fit) {
-            qq[k] = load_xy(sk < C ? (int)list[sk][t] : self);
+            qq[k] = load_xy(sk < C ? (int)list(sk, t) : self);
           } else {
             const int j = sk < C ? -nbr[(size_t)sk * cap + i] - 1 : i;
             qq[k] = sxy[j];
@@ -583,7 +608,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
   }
 
   SC_STAMP(0, 7);
-  // 5. lists out, slot-major: for a fixed slot consecutive threads write consecutive words.
+  // 5. lists out: the thread's row of the table -- its list as it stands in LDS, and the count -- in three 16-byte stores.
   // The table's slots refer to the ranges published in tileBoundsT -- for the usual tile the candidate ranges, for a tile
   // whose candidate ranges exceed pass B's LDS budget the reach of its lists, the entries renumbered (3b above).
   if (ENUM) {
@@ -599,17 +624,23 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
     }
     if (live) {
       C = min(C, kMaxNbr);  // (never more by construction; the rows of the table end there)
+      NbrRow row;
       if (slots_fit) {
         if (trim && !staged) {
           for (int s = 0; s < C; ++s) {
-            const int e = list[s][t];
-            nbr16[(size_t)s * cap + i] = (unsigned short)(e - (e < sr1 ? sub[0] : e < sr2 ? sub[1] : sub[2]));
+            const int e = list(s, t);
+            list(s, t) = (unsigned short)(e - (e < sr1 ? sub[0] : e < sr2 ? sub[1] : sub[2]));
           }
-        } else {
-          for (int s = 0; s < C; ++s) nbr16[(size_t)s * cap + i] = list[s][t];
         }
+#pragma unroll
+        for (int k = 0; k < kMaxNbr / 2; ++k) row.w[k] = list.word(k, t);  // (entries from C on: whatever the scans left there)
+      } else {
+#pragma unroll
+        for (int k = 0; k < kMaxNbr / 2; ++k) row.w[k] = 0u;  // (the entries are in the 32-bit table)
       }
-      cnt[i] = (unsigned char)C;
+      row.w[kRowCount] = (unsigned)C;
+      row.w[11] = 0u;
+      rows[i] = row;
     }
   }
   SC_STAMP(0, 8);
@@ -634,14 +665,15 @@ template <int NOISE, bool ENUM, bool DENS, int CAP, bool STAGE = false>
 __global__ void __launch_bounds__(kTileW)
     k_pass_a(World w, const int* __restrict__ counters, const XY* __restrict__ sxy,
              const int* __restrict__ id, const int* __restrict__ cell, Buckets bk,
-             int* __restrict__ nbr, unsigned short* __restrict__ nbr16, unsigned char* __restrict__ cnt, int cap,
+             int* __restrict__ nbr, NbrRow* __restrict__ rows, int cap,
              const double* __restrict__ eta, const int* __restrict__ offById, double* __restrict__ P, XY* __restrict__ snn,
              const int* __restrict__ tileBounds, int* __restrict__ tileBand,
              int* __restrict__ tileBoundsT) {
   constexpr int kPad = SC_SCAN_BATCH - 1;  // a batched scan may read this far past either end of the tile
   __shared__ XY txy_padded[CAP + 2 * kPad];
   XY* const txy = txy_padded + kPad;
-  __shared__ unsigned short list[kMaxNbr + SC_SCAN_BATCH][kTileW + 2];  // tile slots of the neighbors, [slot][thread]; + spare rows (scan)
+  __shared__ unsigned int list_words[kTileW * kListWords];  // tile slots of the neighbors, a row per thread (Lists)
+  const Lists list{(char*)list_words};
   __shared__ int wkey[6 * (kTileW / 64)];  // the windowed scans' round keys (2 per wave); the lists' reach per range (6 per wave)
 
   const int t = threadIdx.x;
@@ -724,7 +756,7 @@ __global__ void __launch_bounds__(kTileW)
   SC_STAMP(0, 2);
 
   if (in_lds)
-    pass_a_body<NOISE, ENUM, DENS, true, CAP>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, sxy, nbr, nbr16, cnt,
+    pass_a_body<NOISE, ENUM, DENS, true, CAP>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, sxy, nbr, rows,
                                          cap, eta, offById, P, snn, tile_id, tileBoundsT);
   else {
     // Beyond the LDS budget the threads take the block's particles in stride (thread t: particle (t mod 64) * waves +
@@ -748,7 +780,7 @@ __global__ void __launch_bounds__(kTileW)
       em = bk(c - w.ncols + 2);
     }
     pass_a_body<NOISE, ENUM, DENS, false, CAP, STAGE && ENUM && DENS>(w, tl, total, txy, list, wkey, t, ip, livep, idp, e0, b0, b1, e1, bm, em, sxy, nbr,
-                                          nbr16, cnt, cap, eta, offById, P, snn, tile_id, tileBoundsT);
+                                          rows, cap, eta, offById, P, snn, tile_id, tileBoundsT);
   }
 }
 
@@ -775,10 +807,12 @@ struct PairSums {
 // Neither reads a velocity, and gravity in between is a constant, so the two sums are taken together:
 //   dv = sum_j w_j n_ij,   w_j = (dt ss) (ds . n_ij) + (P_i + P_j) dt (1 + pamp) - 2 tp dt,   n_ij = r rinv
 // (one multiply-add chain per pair instead of two accumulations; rounding differs at 1e-16).
-template <int NOISE, bool LDS, bool MON>
+// `entry(s)`: the table entry of slot s (s is a compile-time constant at every call: the loops are unrolled) -- from the
+// row's packed words, or from the 32-bit table of a gigantic tile.
+template <int NOISE, bool LDS, bool MON, class Entry>
 __device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl, const XY* txy, const XY* tss,
                                                  const double* tP, const int self, const int Cn, const int idi,
-                                                 const int (&js)[kMaxNbr], const XY* __restrict__ sxy,
+                                                 const Entry entry, const XY* __restrict__ sxy,
                                                  const double* __restrict__ eta,
                                                  const int* __restrict__ offById, const double* __restrict__ P,
                                                  const XY* __restrict__ snn,
@@ -815,7 +849,7 @@ __device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl,
     if (s < Cn) {
       XY op, os;
       double oP;
-      load(js[s], op, os, oP);
+      load(entry(s), op, os, oP);
       double rx, ry;
       pair_offset<NOISE>(w, zbase + (uint64_t)s * kGold, s, eta, off, ox - op.x, oy - op.y, rx, ry);
       const double rinv = rsqrt_nr(rx * rx + ry * ry);
@@ -840,9 +874,9 @@ __device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl,
 // tension, gravity, pressure, viscosity, wall_bounce, continuous_collision.
 constexpr int kMonPhases = 6;
 constexpr double kNearSteps = 8.0;  // cells a particle may move per tick and still be served by its block's near-segment masks
-template <bool LDS, bool MON>
+template <bool LDS, bool MON, class Entry>
 __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, const XY* tv, const int C, const int Cn,
-                                              const int ws, const int (&js)[kMaxNbr], const XY* __restrict__ svv,
+                                              const int ws, const Entry entry, const XY* __restrict__ svv,
                                               const double* __restrict__ wrec,
                                               const PairSums ps, const double xi, const double yi, const double Pi,
                                               double vxi, double vyi, double& xn, double& yn, double& vxn, double& vyn,
@@ -854,9 +888,9 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
     if (s < Cn) {
       XY ov;
       if constexpr (LDS) {
-        ov = tv[js[s]];
+        ov = tv[entry(s)];
       } else {
-        const int j = entry_index(tl, js[s]);
+        const int j = entry_index(tl, entry(s));
         ov = svv[j];
       }
       ux += ov.x;  // crate.py:175: the neighbors' start-of-tick velocities
@@ -973,8 +1007,7 @@ __global__ void __launch_bounds__(kTileW)
     k_pass_b(World w, int* __restrict__ counters, const XY* __restrict__ sxy, const XY* __restrict__ svv,
              const int* __restrict__ id,
              const int* __restrict__ wslot, const int* __restrict__ cell, const int* __restrict__ nbr,
-             const unsigned short* __restrict__ nbr16,
-             const unsigned char* __restrict__ cnt, int cap, const double* __restrict__ eta,
+             const NbrRow* __restrict__ rows, int cap, const double* __restrict__ eta,
              const int* __restrict__ offById, const double* __restrict__ P, const XY* __restrict__ snn,
              const double* __restrict__ wrec, double* __restrict__ xo,
              double* __restrict__ yo, double* __restrict__ vxo, double* __restrict__ vyo, int* __restrict__ ido,
@@ -1028,18 +1061,16 @@ __global__ void __launch_bounds__(kTileW)
   const int i = i0 + t;
   SC_STAMP_B(0);
   // 1. one round trip: the three ranges (published by pass A for this very block), the particle's
-  // scalars and all twenty table entries -- none of these loads waits for another
+  // scalars and its row of the table (three 16-byte loads) -- none of these loads waits for another
   const int ic = min(i, cap - 1);
   // (a block between the windows may map beyond the last block of the arrays before the live count says so)
   const int* tb = tileBounds + 6 * (BANDED ? min(tile_id, (cap - 1) / kTileW) : tile_id);
   const int tb0 = tb[0], tb1 = tb[1], tb2 = tb[2], tb3 = tb[3], tb4 = tb[4], tb5 = tb[5];
   const int cpacked = cell[ic];
-  const int Craw = cnt[ic];
+  const NbrRow row = rows[ic];
+  const int Craw = (int)row.w[kRowCount];
   const int ws_raw = wslot[ic];
   const int idi = id[ic];
-  int js[kMaxNbr];
-#pragma unroll
-  for (int s = 0; s < kMaxNbr; ++s) js[s] = nbr16[(size_t)s * cap + ic];
   const int n = counters[C_NT];
   if (tile_id == 0 && t == 0 && part != 2) {
     counters[C_NS] = n;    // the storage arrays now hold the n live particles
@@ -1098,11 +1129,12 @@ __global__ void __launch_bounds__(kTileW)
   tl.a2 = tb4;
   tl.n2 = tb5 - tb4;
   const int total = tl.n0 + tl.n1 + tl.n2;
-  if (total > kSlotMax) {  // a block inside one gigantic bucket: its entries are indices in the 32-bit table
-#pragma unroll
-    for (int s = 0; s < kMaxNbr; ++s) js[s] = nbr[(size_t)s * cap + ic];
-  }
   const bool in_lds = total <= kTileCapB;
+  // the table entry of slot s: from the row's packed words (the pair loops keep the ten words, not twenty entries, in
+  // registers); a block inside one gigantic bucket reads indices from the 32-bit table instead
+  const auto entry16 = [&](int s) -> int { return row_entry(row, s); };
+  const bool wide = total > kSlotMax;
+  const auto entry_any = [&](int s) -> int { return wide ? nbr[(size_t)s * cap + ic] : row_entry(row, s); };
   SC_STAMP_VALUE_B(10, total);
   SC_STAMP_VALUE_B(11, tile_id);
   const bool ghost = w.slab && (cpacked & kGhostBit);
@@ -1174,7 +1206,7 @@ __global__ void __launch_bounds__(kTileW)
   double xi = 0, yi = 0, Pi = 0;  // the particle's start-of-tick position and its pressure
   if (in_lds) {
     PairSums ps{0, 0, 0, 0};
-    if (active) ps = pass_b_pairs<NOISE, true, MON>(w, tl, txy, tss, tP, self, Cn, idi, js, sxy, eta, offById, P, snn, xi, yi, Pi);
+    if (active) ps = pass_b_pairs<NOISE, true, MON>(w, tl, txy, tss, tP, self, Cn, idi, entry16, sxy, eta, offById, P, snn, xi, yi, Pi);
     SC_STAMP_B(3);
     __syncthreads();  // everybody is done with (x, y): the array now takes the velocities
 #pragma unroll
@@ -1186,12 +1218,12 @@ __global__ void __launch_bounds__(kTileW)
     SC_STAMP_B(4);
     if (active) {
       idn = idi;
-      pass_b_finish<true, MON>(w, tl, txy, C, Cn, ws, js, svv, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn, mon, near_now);
+      pass_b_finish<true, MON>(w, tl, txy, C, Cn, ws, entry16, svv, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn, mon, near_now);
     }
   } else if (active) {
     idn = idi;
-    const PairSums ps = pass_b_pairs<NOISE, false, MON>(w, tl, txy, tss, tP, self, Cn, idi, js, sxy, eta, offById, P, snn, xi, yi, Pi);
-    pass_b_finish<false, MON>(w, tl, txy, C, Cn, ws, js, svv, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn, mon, near_now);
+    const PairSums ps = pass_b_pairs<NOISE, false, MON>(w, tl, txy, tss, tP, self, Cn, idi, entry_any, sxy, eta, offById, P, snn, xi, yi, Pi);
+    pass_b_finish<false, MON>(w, tl, txy, C, Cn, ws, entry_any, svv, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn, mon, near_now);
   }
   SC_STAMP_B(5);
   if constexpr (MON) {  // sums over the wave, one atomic per wave and phase; [kMonPhases] counts the particles
