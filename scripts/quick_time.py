@@ -9,4 +9,4 @@ s = mk(); s.run(5); s.synchronize()
 t0 = time.perf_counter(); s.run(60); s.synchronize(); el = (time.perf_counter() - t0) / 60
 s = mk(); s.run(5); s.synchronize(); e = s.engine; e.reset_timing(); e.enable_timing(True); s.run(60); s.synchronize(); e.enable_timing(False)
 tm = {k: round(1000*ms/c, 1) for k, (ms, c) in e.timing().items() if c}
-print(f"{tag:60s} tick {el*1e6:7.1f} us  A {tm.get('neighbors_density')}  B {tm.get('force_integrate')}  sort {tm.get('wall_bin')}+{tm.get('cell_scan')}+{tm.get('scatter')}+{tm.get('reorder')}", flush=True)
+print(f"{tag:60s} tick {el*1e6:7.1f} us  A {tm.get('neighbors_density')}  B {tm.get('force_integrate')}  AB {tm.get('neighbors_density_force')}  sort {tm.get('wall_bin')}+{tm.get('cell_scan')}+{tm.get('scatter')}+{tm.get('reorder')}", flush=True)
