@@ -182,7 +182,7 @@ int sc_points_to_segments(int device, const double* xy, int64_t n, const double*
 /* Kernel timing with HIP events on the context's stream.  While enabled every kernel launch is
  * bracketed by two events; sc_get_timing synchronises and returns, per kernel, the summed
  * milliseconds and the number of launches since sc_reset_timing.  Names: sc_kernel_name(i). */
-#define SC_NUM_KERNELS 13
+#define SC_NUM_KERNELS 12
 int sc_enable_timing(sc_ctx* ctx, int on);
 int sc_reset_timing(sc_ctx* ctx);
 int sc_get_timing(sc_ctx* ctx, double* ms /*[SC_NUM_KERNELS]*/, int64_t* launches /*[SC_NUM_KERNELS]*/);

@@ -14,7 +14,7 @@ LIB_PATH = Path(__file__).resolve().parent / "libsandcrate_hip.so"
 MAX_NEIGHBORS = 20
 MAX_SEGMENTS = 16
 MAX_BODIES = 8
-NUM_KERNELS = 13
+NUM_KERNELS = 12
 NOISE_NONE, NOISE_HOST, NOISE_COUNTER = 0, 1, 2
 ERR_CAPACITY = -3
 ERR_STATE = -4

@@ -3,7 +3,6 @@
 // per-tick kernel argument block and enqueues the kernels of sc_kernels.h on one HIP stream.
 // gfx950 (MI355X) only; there is no CPU path in this library.
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 #include <sched.h>
 
 #include <algorithm>
@@ -45,10 +44,10 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(SC_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
-enum KernelId { K_APPEND = 0, K_WALL_BIN, K_SCAN, K_SCATTER, K_REORDER, K_NEIGHBORS, K_NOISE_OFFSETS, K_DENSITY, K_FORCE, K_HALO_PACK, K_HALO_UNPACK, K_PASS_A, K_PASS_AB };
+enum KernelId { K_APPEND = 0, K_WALL_BIN, K_SCAN, K_SCATTER, K_REORDER, K_NEIGHBORS, K_NOISE_OFFSETS, K_DENSITY, K_FORCE, K_HALO_PACK, K_HALO_UNPACK, K_PASS_A };
 const char* kKernelNames[SC_NUM_KERNELS] = {"append",    "wall_bin",      "cell_scan", "scatter", "reorder",
                                             "neighbors", "noise_offsets", "density",   "force_integrate",
-                                            "halo_pack", "halo_unpack", "neighbors_density", "neighbors_density_force"};
+                                            "halo_pack", "halo_unpack", "neighbors_density"};
 
 // Largest s with sqrt(s) <= R.  sqrt is correctly rounded and monotone, so for s >= 0
 // (sqrt(s) <= R) == (s <= threshold): the kernels compare squared distances and skip the sqrt
@@ -85,11 +84,6 @@ struct sc_ctx {
   int* tileBounds = nullptr;   // per block of kTileW sorted particles: its three candidate ranges (k_reorder)
   int* tileBoundsT = nullptr;  // ... the three ranges its neighbor-table slots refer to (the search; sc_tiled.h)
   int* tileBand = nullptr;  // per block of pass A / B: holds a particle that may be packed into a halo message
-  // pass A and pass B in one launch (k_pass_ab): arrival words per block, zero between launches (the waiting block clears
-  // its own); sc_step_begin leaves pass A pending and sc_step_finish launches the pair, unless something asks for pass
-  // A's results in between (flush_pass_a) or the tick is not eligible
-  int* arrive = nullptr;
-  bool fuse_ab = false, a_pending = false;  // (off by default: SANDCRATE_FUSE_PASSES=1; measured in DESIGN.md)
   // halo overlap (sc_set_halo_overlap): the exchange runs on the side stream between the two launches of pass B
   bool overlap = false, band_pending = false;
   bool band_by_flag = false;  // slabs of rows: the split force kernel is ONE launch + a polling kernel on the side stream (sc_set_band_flag)
@@ -421,9 +415,6 @@ int check_flags(int flags) {
     return fail(SC_ERR_HIP, "the halo exchange waited 50 ms for the band blocks of the force kernel and gave up");
   if (flags & F_SCAN_TIMEOUT)
     return fail(SC_ERR_HIP, "the bucket scan waited for a workgroup that never published its total and gave up");
-  if (flags & F_AB_TIMEOUT)
-    return fail(SC_ERR_HIP, "a block of the force pass waited 20 ms for the neighbor pass of the same launch and gave up "
-                "(SANDCRATE_FUSE_PASSES=0 launches the two passes separately)");
   if (flags & F_HALO_LATE)
     return fail(SC_ERR_DOMAIN, "a particle moved more than the band margin (%d columns / %d rows) in one tick and missed the "
                 "overlapped halo message: run without halo overlap", kBandMarginColumns, kBandMarginRows);
@@ -583,54 +574,6 @@ void launch_pass_b_any(sc_ctx* c, bool fused, const WallInputs& wn) {
     launch_pass_b<NOISE, false>(c, wn);
 }
 
-// pass A and pass B in one launch (sc_tiled.h: k_pass_ab) -- the steady state of a run of plain ticks
-bool ab_eligible(const sc_ctx* c) {
-  return c->fuse_ab && !c->custom_grid && c->noise_mode != SC_NOISE_HOST && !c->slab && !c->monitor_on && !piles_expected(c);
-}
-
-template <int NOISE>
-void launch_pass_ab(sc_ctx* c, const WallInputs& wn) {
-  const int cur = (int)(c->tick & 1), nxt = cur ^ 1;
-  const int gridB = tile_grid(c), gridA = (gridB + 7) & ~7;  // (a multiple of 8: block b of either pass lands on the same XCD)
-  Bracket br(c, K_PASS_AB);
-  auto launch = [&](auto kernel) {
-    hipLaunchKernelGGL(kernel, dim3(gridA + gridB), dim3(kTileW), 0, c->stream, c->w, c->counters, c->sxy, c->svv, c->id[1], c->wslotT,
-                       c->cellT, Buckets{c->cellStart}, c->nbr, c->rows, (int)c->cap, c->P, c->snn, c->tileBounds, c->tileBand,
-                       c->tileBoundsT, c->wrec[cur], c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], c->bigHintDev, wn, c->cellS,
-                       c->wslotS, c->cellCount, c->wrec[nxt], c->haloL, c->haloR, c->haloCap, c->arrive, gridA);
-  };
-  // (the narrow pass A tile only: with the wide one the launch needs 135 vector registers, three waves per SIMD)
-  launch(k_pass_ab<NOISE, kTileCapA, false>);
-}
-
-// (experiment) the same pair as two launches, the second one allowed to start before the first has finished
-template <int NOISE>
-void launch_pass_ab_anyorder(sc_ctx* c, const WallInputs& wn) {
-  const int cur = (int)(c->tick & 1), nxt = cur ^ 1;
-  const int grid = tile_grid(c);
-  {
-    Bracket br(c, K_PASS_A);
-    hipLaunchKernelGGL((k_pass_a_sync<NOISE, kTileCapA>), dim3(grid), dim3(kTileW), 0, c->stream, c->w, c->counters, c->sxy, c->id[1],
-                       c->cellT, Buckets{c->cellStart}, c->nbr, c->rows, (int)c->cap, c->P, c->snn, c->tileBounds, c->tileBand,
-                       c->tileBoundsT, c->arrive);
-  }
-  Bracket br(c, K_FORCE);
-  hipExtLaunchKernelGGL((k_pass_b_sync<NOISE>), dim3(grid), dim3(kTileW), 0, c->stream, nullptr, nullptr, hipExtAnyOrderLaunch, c->w,
-                        c->counters, c->sxy, c->svv, c->id[1], c->wslotT, c->cellT, c->nbr, c->rows, (int)c->cap, c->P, c->snn,
-                        c->tileBounds, c->tileBoundsT, c->wrec[cur], c->x[0], c->y[0], c->vx[0], c->vy[0], c->id[0], c->bigHintDev, wn,
-                        c->cellS, c->wslotS, c->cellCount, c->wrec[nxt], c->haloL, c->haloR, c->haloCap, c->arrive);
-}
-
-// pass A of the current tick, if sc_step_begin left it pending (something needs its results before sc_step_finish)
-void flush_pass_a(sc_ctx* c) {
-  if (!c->a_pending) return;
-  c->a_pending = false;
-  if (c->noise_mode == SC_NOISE_COUNTER)
-    launch_pass_a<SC_NOISE_COUNTER, true, true>(c, K_PASS_A);
-  else
-    launch_pass_a<SC_NOISE_NONE, true, true>(c, K_PASS_A);
-}
-
 }  // namespace
 
 extern "C" {
@@ -668,11 +611,8 @@ int sc_create(int device, int64_t capacity, sc_ctx** out) {
   if (e == hipSuccess) e = dalloc(&c->wslotT, n);
   if (e == hipSuccess) e = dalloc(&c->keys, n);
   if (e == hipSuccess) e = dalloc(&c->keyCell, n);
-  if (e == hipSuccess) e = dalloc(&c->tileBounds, kTbStride * (n / kTileW + 2));
-  if (e == hipSuccess) e = dalloc(&c->tileBoundsT, kTbStride * (n / kTileW + 2));
-  if (e == hipSuccess) e = dalloc(&c->arrive, n / kTileW + 2);
-  if (e == hipSuccess) e = hipMemsetAsync(c->arrive, 0, (n / kTileW + 2) * sizeof(int), c->stream);
-  if (const char* f = std::getenv("SANDCRATE_FUSE_PASSES")) c->fuse_ab = std::atoi(f) != 0;
+  if (e == hipSuccess) e = dalloc(&c->tileBounds, 6 * (n / kTileW + 2));
+  if (e == hipSuccess) e = dalloc(&c->tileBoundsT, 6 * (n / kTileW + 2));
   if (e == hipSuccess) e = dalloc(&c->tileBand, n / kTileW + 2);
   if (e == hipSuccess) e = hipMemsetAsync(c->tileBand, 0, (n / kTileW + 2) * sizeof(int), c->stream);
   if (e == hipSuccess) e = dalloc(&c->sortTasks, (size_t)kMaxSortTasks);
@@ -714,7 +654,7 @@ int sc_destroy(sc_ctx* c) {
   }
   if (c->ev_band) (void)hipEventDestroy(c->ev_band);
   if (c->ev_xchg) (void)hipEventDestroy(c->ev_xchg);
-  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->keys, c->keyCell, c->tileBounds, c->tileBoundsT, c->tileBand, c->arrive, c->cellCount, c->cellStart, c->scanDesc, c->sortedStamp, c->sortTasks, c->wrec[0], c->wrec[1],
+  void* ptrs[] = {c->cellS, c->wslotS, c->cellT, c->wslotT, c->keys, c->keyCell, c->tileBounds, c->tileBoundsT, c->tileBand, c->cellCount, c->cellStart, c->scanDesc, c->sortedStamp, c->sortTasks, c->wrec[0], c->wrec[1],
                   c->nbr, c->rows, c->P, c->snn, c->sxy, c->svv, c->counters, c->cntById, c->offById, c->idBlockSums, c->eta,
                   c->stage_xy, c->stage_vxy, c->stage_ids, c->owned_out, c->colHist, c->rng, c->monitor,
                   c->snap_d[0], c->snap_d[1], c->snap_d[2], c->snap_d[3], c->snap_id_d, c->snap_rng_d};
@@ -771,8 +711,6 @@ int sc_synchronize(sc_ctx* c) {
   if (!c->in_step) c->upper = h[C_NS];
   if (h[C_FLAGS]) {
     HIPCHK(hipMemsetAsync(c->counters + C_FLAGS, 0, sizeof(int), c->stream));
-    if (h[C_FLAGS] & F_AB_TIMEOUT)  // arrivals of the abandoned wait may have come in late: the words start the next launch at zero
-      HIPCHK(hipMemsetAsync(c->arrive, 0, (c->cap / kTileW + 2) * sizeof(int), c->stream));
     return check_flags(h[C_FLAGS]);
   }
   return SC_OK;
@@ -901,8 +839,6 @@ int sc_step_begin(sc_ctx* c) {
   // indexed once every count is known.  Otherwise the search and pass A are one launch.
   if (c->noise_mode == SC_NOISE_HOST || c->custom_grid)
     launch_pass_a<SC_NOISE_NONE, true, false>(c, K_NEIGHBORS);
-  else if (ab_eligible(c))
-    c->a_pending = true;  // sc_step_finish launches it together with pass B
   else if (c->noise_mode == SC_NOISE_COUNTER)
     launch_pass_a<SC_NOISE_COUNTER, true, true>(c, K_PASS_A);
   else
@@ -926,7 +862,6 @@ int sc_step_begin(sc_ctx* c) {
 int sc_step_stats(sc_ctx* c, sc_stats* out) {
   if (!c || !out) return fail(SC_ERR_ARG, "null argument");
   if (!c->in_step) return fail(SC_ERR_STATE, "sc_step_stats needs sc_step_begin first");
-  flush_pass_a(c);
   hipLaunchKernelGGL(k_count_stats, dim3(1), dim3(kBlock), 0, c->stream, c->counters, (const unsigned int*)c->rows, c->wslotT);
   int h[C_COUNT];
   int rc = read_counters(c, h);
@@ -992,24 +927,12 @@ int sc_step_finish(sc_ctx* c) {
                          c->tick + 1);
     if (rc) return rc;
     if (next.nrows != c->w.nrows || next.ncols != c->w.ncols) {
-      flush_pass_a(c);  // (a pending pass A reads this tick's bucket starts: before they may be re-allocated)
       rc = ensure_cells(c, (int64_t)next.nrows * next.ncols);  // the radius changed: the grid may have grown
       if (rc) return rc;
     }
     wn = wall_inputs_of(next);
   }
   c->have_next = false;
-  if (c->a_pending && fused && ab_eligible(c)) {  // the pair in one launch
-    c->a_pending = false;
-    static const bool anyorder = std::getenv("SANDCRATE_ANYORDER") != nullptr;
-    if (anyorder && c->noise_mode == SC_NOISE_COUNTER)
-      launch_pass_ab_anyorder<SC_NOISE_COUNTER>(c, wn);
-    else if (c->noise_mode == SC_NOISE_COUNTER)
-      launch_pass_ab<SC_NOISE_COUNTER>(c, wn);
-    else
-      launch_pass_ab<SC_NOISE_NONE>(c, wn);
-  } else {
-  flush_pass_a(c);
   switch (c->noise_mode) {
     case SC_NOISE_HOST:
       launch_pass_a<SC_NOISE_HOST, false, true>(c, K_DENSITY);
@@ -1020,7 +943,6 @@ int sc_step_finish(sc_ctx* c) {
       if (c->custom_grid) launch_pass_a<SC_NOISE_NONE, false, true>(c, K_DENSITY);
       launch_pass_b_any<SC_NOISE_NONE>(c, fused, wn);
       break;
-  }
   }
   if (fused) {
     c->prebinned = true;
@@ -1184,7 +1106,6 @@ int sc_download_neighbors(sc_ctx* c, int64_t* ids, int32_t* counts, int64_t* nei
                           int64_t* n_out) {
   if (!c) return fail(SC_ERR_ARG, "null context");
   if (!c->in_step) return fail(SC_ERR_STATE, "sc_download_neighbors is valid between sc_step_begin and sc_step_finish");
-  flush_pass_a(c);
   int h[C_COUNT];
   int rc = read_counters(c, h);
   if (rc) return rc;
@@ -1196,8 +1117,8 @@ int sc_download_neighbors(sc_ctx* c, int64_t* ids, int32_t* counts, int64_t* nei
   std::vector<double> hxy(2 * n);
   std::vector<int> slot(n);
   const int64_t nblocks = (n + kTileW - 1) / kTileW;
-  std::vector<int> tb(kTbStride * std::max<int64_t>(nblocks, 1));
-  if ((rc = fetch(c, tb.data(), c->tileBoundsT, kTbStride * nblocks * sizeof(int)))) return rc;
+  std::vector<int> tb(6 * std::max<int64_t>(nblocks, 1));
+  if ((rc = fetch(c, tb.data(), c->tileBoundsT, 6 * nblocks * sizeof(int)))) return rc;
   if ((rc = fetch(c, id.data(), c->id[1], n * sizeof(int))) || (rc = fetch(c, rows.data(), c->rows, n * sizeof(NbrRow))) ||
       (rc = fetch(c, hxy.data(), c->sxy, 2 * n * sizeof(double))))
     return rc;
@@ -1205,7 +1126,7 @@ int sc_download_neighbors(sc_ctx* c, int64_t* ids, int32_t* counts, int64_t* nei
   if (neighbors)
     for (int64_t k = 0; k < n * kMaxNbr; ++k) neighbors[k] = -1;
   auto tile_of = [&](int64_t k) {  // the table holds tile slots of the particle's block
-    const int* b = tb.data() + kTbStride * (k / kTileW);
+    const int* b = tb.data() + 6 * (k / kTileW);
     return Tile{b[0], b[1] - b[0], b[2], b[3] - b[2], b[4], b[5] - b[4]};
   };
   bool any_big = false;  // a block whose tile exceeds 16-bit slots: the 32-bit table holds -(index + 1)

@@ -108,7 +108,7 @@ enum Counter {
   C_ALLOC = 96
 };
 
-enum Flag { F_OUT_OF_GRID = 1, F_NAN = 2, F_HALO_OVERFLOW = 4, F_CAPACITY = 8, F_HALO_LATE = 16, F_BAND_TIMEOUT = 32, F_SCAN_TIMEOUT = 64, F_AB_TIMEOUT = 128 };
+enum Flag { F_OUT_OF_GRID = 1, F_NAN = 2, F_HALO_OVERFLOW = 4, F_CAPACITY = 8, F_HALO_LATE = 16, F_BAND_TIMEOUT = 32, F_SCAN_TIMEOUT = 64 };
 
 // columns / rows a particle may move in one tick and still be packed in time (halo overlap).  With slabs of rows the
 // band blocks are few whatever the margin; with columns every row has them, and each column of margin adds as many.

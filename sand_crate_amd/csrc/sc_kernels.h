@@ -952,13 +952,13 @@ __global__ void __launch_bounds__(kReorderBlock)
   // the block's first and last particle know them from their cells.  Published here, one kernel ahead of the
   // tiled passes, so that those can stage their tile without waiting for bucket lookups of their own.
   if (dst % SC_TILE_W == 0) {
-    int* tb = tileBounds + 8 * (dst / SC_TILE_W);
+    int* tb = tileBounds + 6 * (dst / SC_TILE_W);
     tb[0] = bk(c - 1);
     tb[2] = bk(c + ncols - 1);
     tb[4] = bk(c - ncols - 1);
   }
   if (dst % SC_TILE_W == SC_TILE_W - 1 || dst == nlive - 1) {
-    int* tb = tileBounds + 8 * (dst / SC_TILE_W);
+    int* tb = tileBounds + 6 * (dst / SC_TILE_W);
     tb[1] = bk(c + 2);
     tb[3] = bk(c + ncols + 2);
     tb[5] = bk(c - ncols + 2);

@@ -74,78 +74,6 @@ struct Lists {
   __device__ __forceinline__ unsigned int& word(int k, int t) const { return *(unsigned int*)(base + t * kListStride + 4 * k); }
 };
 
-// ------------------------------------------------------------------------------------------
-// Hand-offs inside ONE launch (k_pass_ab: pass A's blocks and pass B's blocks in one grid).  What pass A leaves for
-// pass B -- P, the surface normals, the table rows, the published ranges -- is then read by workgroups on other CUs and
-// other XCDs (private L2s) while the launch is still running: the producer stores write-through (`sc1`), every storing
-// wave drains its stores, one lane signals with agent-scope atomic adds; the consumer polls ONE word and then reads
-// every handed-off byte with `sc1` loads, which bypass its CU's L1.  (Every line of those arrays is written whole by
-// one block -- a block's share of each array is a multiple of 128 bytes --, and a consumer reads a line only after the
-// block that writes it has signalled: no cache can hold an older copy from this launch.)  SYNC = false: the plain forms,
-// for the launches that hand over at a kernel boundary.
-typedef unsigned int U4 __attribute__((ext_vector_type(4)));
-typedef unsigned int U2 __attribute__((ext_vector_type(2)));
-template <bool SYNC>
-struct G {
-  // `base`: a wave-uniform pointer (a kernel argument plus a block-uniform offset); `off`: bytes from it, below 2^32
-  static __device__ __forceinline__ void st16(void* base, unsigned off, const U4 v) {
-#ifdef SC_AB_PLAINSTORE
-    if constexpr (false)
-#else
-    if constexpr (SYNC)
-#endif
-      __builtin_amdgcn_raw_buffer_store_b128(v, __builtin_amdgcn_make_buffer_rsrc(base, 0, -1, 0x00020000), off, 0, 16);
-    else
-      *(U4*)((char*)base + off) = v;
-  }
-  static __device__ __forceinline__ U4 ld16(const void* base, unsigned off) {
-    if constexpr (SYNC)
-      return __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000), off, 0, 16);
-    else
-      return *(const U4*)((const char*)base + off);
-  }
-  static __device__ __forceinline__ void st8(double* p, double v) {
-#ifdef SC_AB_PLAINSTORE
-    if constexpr (false)
-#else
-    if constexpr (SYNC)
-#endif
-      __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-      *p = v;
-  }
-  static __device__ __forceinline__ double ld8(const void* base, unsigned off) {
-    if constexpr (SYNC) {
-      const U2 v = __builtin_amdgcn_raw_buffer_load_b64(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000), off, 0, 16);
-      return __hiloint2double((int)v.y, (int)v.x);
-    } else {
-      return *(const double*)((const char*)base + off);
-    }
-  }
-  static __device__ __forceinline__ void st4(int* p, int v) {
-    if constexpr (SYNC)
-      __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-      *p = v;
-  }
-  static __device__ __forceinline__ int ld4(const int* p) {
-    if constexpr (SYNC)
-      return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-      return *p;
-  }
-  static __device__ __forceinline__ XY ldxy(const XY* base, int j) {
-    const U4 v = ld16(base, (unsigned)j * 16u);
-    return XY{__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z)};
-  }
-  static __device__ __forceinline__ void stxy(XY* base, int j, const XY q) {
-    st16(base, (unsigned)j * 16u,
-         U4{(unsigned)__double2loint(q.x), (unsigned)__double2hiint(q.x), (unsigned)__double2loint(q.y), (unsigned)__double2hiint(q.y)});
-  }
-};
-
-constexpr int kTbStride = 8;  // ints per block in tileBounds / tileBoundsT: six bounds, padded to two 16-byte words
-
 struct Tile {
   int a0, n0;  // same rows
   int a1, n1;  // next rows
@@ -182,8 +110,8 @@ __device__ __forceinline__ double rsqrt_nr(double s) {
 // `tiles`: the blocks expected to hold particles.  A slab's grid is sized by its capacity; dealing ALL of it into
 // runs would give the last XCDs nothing but empty blocks (measured on a slab with 30 % slack: pass A +15 %, pass B
 // +13 %).  Blocks beyond `tiles` keep their own index.
-__device__ __forceinline__ int tile_of_block(int tiles, int b, int grid) {
-  const int nb = min(grid, tiles);
+__device__ __forceinline__ int tile_of_block(int tiles) {
+  const int nb = min((int)gridDim.x, tiles), b = blockIdx.x;
   if (b >= nb) return b;
   const int q = nb >> 3, r = nb & 7, xcd = b & 7;
   return xcd * q + min(xcd, r) + (b >> 3);
@@ -194,8 +122,8 @@ __device__ __forceinline__ int tiles_expected(const World& w) { return (w.live_h
 // kernel ends with its slowest block: in a pile-up those are the blocks beside the piles along the floor and the
 // ceiling -- the first tiles of the first XCD's run and the last tiles of the last one's, which in plain order start
 // when everything else is nearly done.  Two contiguous fronts per XCD keep the overlaps in its L2 as before.
-__device__ __forceinline__ int tile_of_block_ends_first(int tiles, int b, int grid) {
-  const int nb = min(grid, tiles);
+__device__ __forceinline__ int tile_of_block_ends_first(int tiles) {
+  const int nb = min((int)gridDim.x, tiles), b = blockIdx.x;
   if (b >= nb) return b;
   const int q = nb >> 3, r = nb & 7, xcd = b & 7;
   const int start = xcd * q + min(xcd, r), len = q + (xcd < r ? 1 : 0), l = b >> 3;
@@ -203,7 +131,7 @@ __device__ __forceinline__ int tile_of_block_ends_first(int tiles, int b, int gr
 }
 
 // Phases 3-5 of pass A for one particle.  LDS: where the tile is (compile time, see the header).
-template <int NOISE, bool ENUM, bool DENS, bool LDS, int CAP, bool STAGE = false, bool SYNC = false>
+template <int NOISE, bool ENUM, bool DENS, bool LDS, int CAP, bool STAGE = false>
 __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, const int total, XY* txy,
                                             const Lists list, int* wkey, const int t, const int i,
                                             const bool live, const int idi, const int e0, const int b0, const int b1,
@@ -212,7 +140,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
                                             NbrRow* __restrict__ rows, const int cap,
                                             const double* __restrict__ eta, const int* __restrict__ offById,
                                             double* __restrict__ P, XY* __restrict__ snn,
-                                            const int tile_id, int* __restrict__ tileBoundsT, bool* trimmed = nullptr) {
+                                            const int tile_id, int* __restrict__ tileBoundsT) {
   auto load_xy = [&](int slot) -> XY {
     if constexpr (LDS) {
       return txy[slot];
@@ -478,7 +406,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       // entries go straight to the table as -(index+1); correctness path only
       const double xi = pi.x, yi = pi.y;
       const double xhi = xi + w.d, xlo = xi - w.d;
-      auto push = [&](int j) { G<SYNC>::st4(&nbr[(size_t)C++ * cap + i], -j - 1); };
+      auto push = [&](int j) { nbr[(size_t)C++ * cap + i] = -j - 1; };
       for (int j = i + 1; j < e0 && C < kMaxNbr; ++j) {
         const XY pj = sxy[j];
         const double xj = pj.x;
@@ -675,8 +603,8 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       ax += g * rx;
       ay += g * ry;
     }
-    G<SYNC>::st8(&P[i], C ? fmax(((double)C - sumc) - w.ignored, 0.0) : 0.0);  // crate.py:265-273
-    G<SYNC>::stxy(snn + tile_id * kTileW, i - tile_id * kTileW, XY{ax, ay});
+    P[i] = C ? fmax(((double)C - sumc) - w.ignored, 0.0) : 0.0;  // crate.py:265-273
+    snn[i] = XY{ax, ay};
   }
 
   SC_STAMP(0, 7);
@@ -691,11 +619,9 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       reach(nb, sub);
     }
     if (t == 0) {
-      int* tbT = tileBoundsT + kTbStride * tile_id;
-      G<SYNC>::st16(tbT, 0, U4{(unsigned)nb[0], (unsigned)nb[1], (unsigned)nb[2], (unsigned)nb[3]});
-      G<SYNC>::st16(tbT, 16, U4{(unsigned)nb[4], (unsigned)nb[5], 0u, 0u});
+      int* tbT = tileBoundsT + 6 * tile_id;
+      tbT[0] = nb[0]; tbT[1] = nb[1]; tbT[2] = nb[2]; tbT[3] = nb[3]; tbT[4] = nb[4]; tbT[5] = nb[5];
     }
-    if (trimmed) *trimmed = trim;
     if (live) {
       C = min(C, kMaxNbr);  // (never more by construction; the rows of the table end there)
       NbrRow row;
@@ -714,11 +640,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       }
       row.w[kRowCount] = (unsigned)C;
       row.w[11] = 0u;
-      NbrRow* const rbase = rows + tile_id * kTileW;  // (block-uniform)
-      const unsigned roff = (unsigned)(i - tile_id * kTileW) * (unsigned)sizeof(NbrRow);
-      G<SYNC>::st16(rbase, roff, U4{row.w[0], row.w[1], row.w[2], row.w[3]});
-      G<SYNC>::st16(rbase, roff + 16, U4{row.w[4], row.w[5], row.w[6], row.w[7]});
-      G<SYNC>::st16(rbase, roff + 32, U4{row.w[8], row.w[9], row.w[10], row.w[11]});
+      rows[i] = row;
     }
   }
   SC_STAMP(0, 8);
@@ -739,45 +661,24 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
 // STAGE: tiles searched through the window stage the reach of their lists for the pair math (pass_a_body, 3b).  Its own
 // instantiation, launched while the scans report big buckets: inlined into the one kernel the extra paths cost the
 // uniform regime 13 spilled scalar registers and 1 us per tick.
-// LDS of one pass A block (k_pass_a declares it; k_pass_ab carves it out of the launch's one array)
-template <int CAP>
-struct PassALds {
-  static constexpr int kPad = SC_SCAN_BATCH - 1;  // a batched scan may read this far past either end of the tile
-  XY txy_padded[CAP + 2 * kPad];
-  unsigned int list_words[kTileW * kListWords];  // tile slots of the neighbors, a row per thread (Lists)
-  int wkey[6 * (kTileW / 64)];  // the windowed scans' round keys (2 per wave); the lists' reach per range (6 per wave)
-};
-
-// The tiles whose particles lie in a block's three candidate ranges (tileBounds): per range the first and the last tile.
-// Pass A's block u adds one to the arrival word of every tile in them when its outputs are out; pass B's block t waits for
-// as many arrivals as its own ranges have tiles -- the relation is symmetric (u's particles are candidates of t's exactly
-// when t's are candidates of u's: same rows <-> same rows, next rows <-> previous rows), so the two counts agree.
-struct Cover {
-  int lo[3], hi[3];  // hi < lo: an empty range
-  __device__ __forceinline__ Cover(int tb0, int tb1, int tb2, int tb3, int tb4, int tb5) {
-    lo[0] = tb0 / kTileW; hi[0] = tb1 > tb0 ? (tb1 - 1) / kTileW : lo[0] - 1;
-    lo[1] = tb2 / kTileW; hi[1] = tb3 > tb2 ? (tb3 - 1) / kTileW : lo[1] - 1;
-    lo[2] = tb4 / kTileW; hi[2] = tb5 > tb4 ? (tb5 - 1) / kTileW : lo[2] - 1;
-  }
-  __device__ __forceinline__ int tiles() const { return (hi[0] - lo[0] + 1) + (hi[1] - lo[1] + 1) + (hi[2] - lo[2] + 1); }
-};
-constexpr int kArriveTrimmed = 1 << 16;  // added to a block's own arrival word: its table refers to trimmed ranges (tileBoundsT)
-
-// One block of pass A.  `vb` of `vgrid`: the block's index among pass A's blocks.  SYNC (k_pass_ab): the outputs are
-// stored write-through and the block signals its arrival to the tiles that need it (`arrive`).
-template <int NOISE, bool ENUM, bool DENS, int CAP, bool STAGE, bool SYNC>
-__device__ __forceinline__ void pass_a_block(const World& w, const int* __restrict__ counters, const XY* __restrict__ sxy,
+template <int NOISE, bool ENUM, bool DENS, int CAP, bool STAGE = false>
+__global__ void __launch_bounds__(kTileW)
+    k_pass_a(World w, const int* __restrict__ counters, const XY* __restrict__ sxy,
              const int* __restrict__ id, const int* __restrict__ cell, Buckets bk,
              int* __restrict__ nbr, NbrRow* __restrict__ rows, int cap,
              const double* __restrict__ eta, const int* __restrict__ offById, double* __restrict__ P, XY* __restrict__ snn,
              const int* __restrict__ tileBounds, int* __restrict__ tileBand,
-             int* __restrict__ tileBoundsT, PassALds<CAP>& lds, const int vb, const int vgrid, int* __restrict__ arrive) {
-  XY* const txy = lds.txy_padded + PassALds<CAP>::kPad;
-  const Lists list{(char*)lds.list_words};
-  int* const wkey = lds.wkey;
+             int* __restrict__ tileBoundsT) {
+  constexpr int kPad = SC_SCAN_BATCH - 1;  // a batched scan may read this far past either end of the tile
+  __shared__ XY txy_padded[CAP + 2 * kPad];
+  XY* const txy = txy_padded + kPad;
+  __shared__ unsigned int list_words[kTileW * kListWords];  // tile slots of the neighbors, a row per thread (Lists)
+  const Lists list{(char*)list_words};
+  __shared__ int wkey[6 * (kTileW / 64)];  // the windowed scans' round keys (2 per wave); the lists' reach per range (6 per wave)
 
   const int t = threadIdx.x;
-  const int tile_id = tile_of_block_ends_first(tiles_expected(w), vb, vgrid);
+  SC_TIMELINE_KERNEL(0);
+  const int tile_id = tile_of_block_ends_first(tiles_expected(w));
   const int i0 = tile_id * kTileW;
   const int i = i0 + t;
   SC_STAMP(0, 0);
@@ -786,7 +687,7 @@ __device__ __forceinline__ void pass_a_block(const World& w, const int* __restri
   const int cpacked = cell[ic];
   const int idi = (DENS && NOISE != SC_NOISE_NONE) ? id[ic] : 0;
   // the tile's three ranges: k_reorder published them, so staging need not wait for the bucket lookups below
-  const int* tb = tileBounds + kTbStride * tile_id;
+  const int* tb = tileBounds + 6 * tile_id;
   const int tb0 = tb[0], tb1 = tb[1], tb2 = tb[2], tb3 = tb[3], tb4 = tb[4], tb5 = tb[5];
   const int n = counters[C_NT];
   if (i0 >= n) return;
@@ -854,10 +755,9 @@ __device__ __forceinline__ void pass_a_block(const World& w, const int* __restri
   __syncthreads();
   SC_STAMP(0, 2);
 
-  bool trimmed = false;  // (block-uniform) the table refers to trimmed ranges
   if (in_lds)
-    pass_a_body<NOISE, ENUM, DENS, true, CAP, false, SYNC>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, sxy, nbr, rows,
-                                         cap, eta, offById, P, snn, tile_id, tileBoundsT, &trimmed);
+    pass_a_body<NOISE, ENUM, DENS, true, CAP>(w, tl, total, txy, list, wkey, t, i, live, idi, e0, b0, b1, e1, bm, em, sxy, nbr, rows,
+                                         cap, eta, offById, P, snn, tile_id, tileBoundsT);
   else {
     // Beyond the LDS budget the threads take the block's particles in stride (thread t: particle (t mod 64) * waves +
     // t / 64).  Consecutive particles share their surroundings, and the expensive ones -- sparse particles beside a
@@ -879,37 +779,9 @@ __device__ __forceinline__ void pass_a_block(const World& w, const int* __restri
       bm = bk(c - w.ncols - 1);
       em = bk(c - w.ncols + 2);
     }
-    pass_a_body<NOISE, ENUM, DENS, false, CAP, STAGE && ENUM && DENS, SYNC>(w, tl, total, txy, list, wkey, t, ip, livep, idp, e0, b0, b1, e1, bm, em, sxy, nbr,
-                                          rows, cap, eta, offById, P, snn, tile_id, tileBoundsT, &trimmed);
+    pass_a_body<NOISE, ENUM, DENS, false, CAP, STAGE && ENUM && DENS>(w, tl, total, txy, list, wkey, t, ip, livep, idp, e0, b0, b1, e1, bm, em, sxy, nbr,
+                                          rows, cap, eta, offById, P, snn, tile_id, tileBoundsT);
   }
-  if constexpr (SYNC) {
-    // the hand-off: every wave's stores have been acknowledged, then ONE wave signals -- an agent-scope add to the
-    // arrival word of every tile in this block's cover (its own among them: range 0 holds the block's particles)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t < 64) {
-      const Cover cv(tb0, tb1, tb2, tb3, tb4, tb5);
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-        for (int u = cv.lo[k] + t; u <= cv.hi[k]; u += 64)
-          __hip_atomic_fetch_add(&arrive[u], 1 + ((k == 0 && u == tile_id && trimmed) ? kArriveTrimmed : 0), __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
-template <int NOISE, bool ENUM, bool DENS, int CAP, bool STAGE = false>
-__global__ void __launch_bounds__(kTileW)
-    k_pass_a(World w, const int* __restrict__ counters, const XY* __restrict__ sxy,
-             const int* __restrict__ id, const int* __restrict__ cell, Buckets bk,
-             int* __restrict__ nbr, NbrRow* __restrict__ rows, int cap,
-             const double* __restrict__ eta, const int* __restrict__ offById, double* __restrict__ P, XY* __restrict__ snn,
-             const int* __restrict__ tileBounds, int* __restrict__ tileBand,
-             int* __restrict__ tileBoundsT) {
-  __shared__ PassALds<CAP> lds;
-  SC_TIMELINE_KERNEL((w.tick & 1) ? 5 : 0);  // (diagnostic build: odd ticks in the sorting kernel's slot, see k_pass_ab)
-  pass_a_block<NOISE, ENUM, DENS, CAP, STAGE, false>(w, counters, sxy, id, cell, bk, nbr, rows, cap, eta, offById, P, snn, tileBounds,
-                                                     tileBand, tileBoundsT, lds, blockIdx.x, gridDim.x, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -937,7 +809,7 @@ struct PairSums {
 // (one multiply-add chain per pair instead of two accumulations; rounding differs at 1e-16).
 // `entry(s)`: the table entry of slot s (s is a compile-time constant at every call: the loops are unrolled) -- from the
 // row's packed words, or from the 32-bit table of a gigantic tile.
-template <int NOISE, bool LDS, bool MON, bool SYNC, class Entry>
+template <int NOISE, bool LDS, bool MON, class Entry>
 __device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl, const XY* txy, const XY* tss,
                                                  const double* tP, const int self, const int Cn, const int idi,
                                                  const Entry entry, const XY* __restrict__ sxy,
@@ -1130,19 +1002,9 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
 // no look-ahead -- does not overwrite the tick before it)
 #define SC_STAMP_B(slot) SC_STAMP((w.tick & 1) ? 3 : 1, slot)
 #define SC_STAMP_VALUE_B(slot, value) SC_STAMP_VALUE((w.tick & 1) ? 3 : 1, slot, value)
-struct PassBLds {
-  XY txy[kTileCapB];   // (x, y) of the tile; (vx, vy) once the pair loop is done
-  XY tss[kTileCapB];   // (sx, sy)
-  double tP[kTileCapB];
-};
-constexpr long long kArriveTimeout = 2000000LL;  // 20 ms of the 100 MHz clock: a block of pass A that never arrives
-
-// One block of pass B.  `vb` of `vgrid`: the block's index among pass B's blocks.  SYNC (k_pass_ab): the blocks of pass A
-// run in the same launch -- the block waits for the arrivals of the tiles its ranges need (`arrive`; `tileBoundsK`: the
-// candidate ranges k_reorder published, which say which tiles those are) and reads what pass A wrote with `sc1` loads.
-template <int NOISE, bool FUSED, bool MON, bool GROUP, bool BANDED, bool SYNC>
-__device__ __forceinline__ void
-    pass_b_block(const World& w, int* __restrict__ counters, const XY* __restrict__ sxy, const XY* __restrict__ svv,
+template <int NOISE, bool FUSED, bool MON = false, bool GROUP = false, bool BANDED = false>
+__global__ void __launch_bounds__(kTileW)
+    k_pass_b(World w, int* __restrict__ counters, const XY* __restrict__ sxy, const XY* __restrict__ svv,
              const int* __restrict__ id,
              const int* __restrict__ wslot, const int* __restrict__ cell, const int* __restrict__ nbr,
              const NbrRow* __restrict__ rows, int cap, const double* __restrict__ eta,
@@ -1150,18 +1012,17 @@ __device__ __forceinline__ void
              const double* __restrict__ wrec, double* __restrict__ xo,
              double* __restrict__ yo, double* __restrict__ vxo, double* __restrict__ vyo, int* __restrict__ ido,
              const int* __restrict__ tileBounds, volatile int* __restrict__ progress,
-             const WallInputs& wn, int* __restrict__ cellS, int* __restrict__ wslotS, int* __restrict__ cellCount,
+             WallInputs wn, int* __restrict__ cellS, int* __restrict__ wslotS, int* __restrict__ cellCount,
              double* __restrict__ wrec_next, double* __restrict__ haloL,
              double* __restrict__ haloR, int haloCap, double* __restrict__ monitor, const int* __restrict__ tileBand,
-             int part, int bandw, int epoch, PassBLds& lds, const int vb, const int vgrid,
-             const int* __restrict__ tileBoundsK, int* __restrict__ arrive) {
+             int part, int bandw, int epoch) {
   static_assert(!(MON && FUSED), "the force monitor runs with the plain force kernel");
-  static_assert(!(SYNC && BANDED), "the one-launch form has no band windows");
-  XY* const txy = lds.txy;
-  XY* const tss = lds.tss;
-  double* const tP = lds.tP;
+  __shared__ XY txy[kTileCapB];   // (x, y) of the tile; (vx, vy) once the pair loop is done
+  __shared__ XY tss[kTileCapB];   // (sx, sy)
+  __shared__ double tP[kTileCapB];
 
   const int t = threadIdx.x;
+  SC_TIMELINE_KERNEL((w.tick & 1) ? 6 : 1);
   // part 1 / 2: the blocks with / without band particles only (halo overlap: two launches, the exchange starts
   // between them); 0: all blocks.  bandw > 0 (slabs of rows: the band blocks are the first and last of the sorted
   // order): part 1 is a launch of 2 bandw workgroups over the first and the last bandw blocks -- a small kernel
@@ -1174,7 +1035,7 @@ __device__ __forceinline__ void
   int tile_id;
   bool window_block = false, between = false;
   if (BANDED && (part == 1 || part == 3) && bandw > 0) {
-    const int b = vb;
+    const int b = blockIdx.x;
     if (b < bandw) {  // the low window
       tile_id = b;
       window_block = part == 3;
@@ -1184,7 +1045,7 @@ __device__ __forceinline__ void
       if (tile_id < bandw) return;  // fewer than 2 bandw blocks: the low window has them
       window_block = part == 3;
     } else {  // part 3: the blocks between the windows, bandw .. nt - bandw - 1 (checked once the count is here)
-      const int nb = min(vgrid - 2 * bandw, max(tiles_expected(w) - 2 * bandw, 0)), ib = b - 2 * bandw;
+      const int nb = min((int)gridDim.x - 2 * bandw, max(tiles_expected(w) - 2 * bandw, 0)), ib = b - 2 * bandw;
       int k = ib;
       if (ib < nb) {
         const int q = nb >> 3, r = nb & 7, xcd = ib & 7;
@@ -1194,12 +1055,7 @@ __device__ __forceinline__ void
       between = true;
     }
   } else {
-    // (one launch with pass A: the same order as pass A's blocks, so that the tiles whose arrivals come first are asked for first)
-#ifdef SC_AB_BORDER_PLAIN
-    tile_id = tile_of_block(tiles_expected(w), vb, vgrid);
-#else
-    tile_id = SYNC ? tile_of_block_ends_first(tiles_expected(w), vb, vgrid) : tile_of_block(tiles_expected(w), vb, vgrid);
-#endif
+    tile_id = tile_of_block(tiles_expected(w));
   }
   const int i0 = tile_id * kTileW;
   const int i = i0 + t;
@@ -1208,20 +1064,14 @@ __device__ __forceinline__ void
   // scalars and its row of the table (three 16-byte loads) -- none of these loads waits for another
   const int ic = min(i, cap - 1);
   // (a block between the windows may map beyond the last block of the arrays before the live count says so)
-  // (SYNC: the candidate ranges of k_reorder -- what the table refers to unless pass A says it trimmed them)
-  const int* tb = (SYNC ? tileBoundsK : tileBounds) + kTbStride * (BANDED ? min(tile_id, (cap - 1) / kTileW) : tile_id);
-  int tb0 = tb[0], tb1 = tb[1], tb2 = tb[2], tb3 = tb[3], tb4 = tb[4], tb5 = tb[5];
+  const int* tb = tileBounds + 6 * (BANDED ? min(tile_id, (cap - 1) / kTileW) : tile_id);
+  const int tb0 = tb[0], tb1 = tb[1], tb2 = tb[2], tb3 = tb[3], tb4 = tb[4], tb5 = tb[5];
   const int cpacked = cell[ic];
+  const NbrRow row = rows[ic];
+  const int Craw = (int)row.w[kRowCount];
   const int ws_raw = wslot[ic];
   const int idi = id[ic];
   const int n = counters[C_NT];
-  NbrRow row;
-  if constexpr (!SYNC) row = rows[ic];
-  int got = 0;  // SYNC: the block's arrival word, asked for with the first round trip (the count to expect comes with the bounds)
-#ifndef SC_AB_NOPOLL
-  if constexpr (SYNC)
-    if (t == 0) got = __hip_atomic_load(&arrive[min(tile_id, (cap - 1) / kTileW)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
   if (tile_id == 0 && t == 0 && part != 2) {
     counters[C_NS] = n;    // the storage arrays now hold the n live particles
     counters[C_SUMC] = 0;  // per-tick counters start the next tick at zero (sc_step_stats reads them
@@ -1235,7 +1085,7 @@ __device__ __forceinline__ void
     progress[2] = n;           // ... and sizes heuristics by a recent live count
     progress[3] = counters[C_NEXT_ID];  // ... and keeps its bound of the ids handed out near the device's count (sc_emit_particles)
   }
-  if (BANDED && part == 3 && n == 0 && vb == 0 && t == 0)  // nothing at all: nobody else would publish the epoch
+  if (BANDED && part == 3 && n == 0 && blockIdx.x == 0 && t == 0)  // nothing at all: nobody else would publish the epoch
     __hip_atomic_store(&counters[C_BAND_FLAG], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (i0 >= n) return;
   if (BANDED && between && tile_id >= (n + kTileW - 1) / kTileW - bandw) return;  // that block belongs to the high window
@@ -1247,39 +1097,6 @@ __device__ __forceinline__ void
   } else if (BANDED && part == 3) {
     late_block = !window_block;
   }
-  if constexpr (SYNC) {
-    // wait for pass A: as many arrivals as the block's candidate ranges have tiles (Cover).  One lane polls the one word
-    // (relaxed, bounded) and clears it for the next launch -- every adder has arrived --; the barrier lets the others go.
-    if (t == 0) {
-      const int need = Cover(tb0, tb1, tb2, tb3, tb4, tb5).tiles();
-      const long long t0 = wall_clock64();
-#ifdef SC_AB_NOPOLL
-      got = need;
-#endif
-      while ((got & (kArriveTrimmed - 1)) != need) {
-        if (wall_clock64() - t0 > kArriveTimeout) {
-          atomicOr(&counters[C_FLAGS], F_AB_TIMEOUT);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(8);
-        got = __hip_atomic_load(&arrive[tile_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __hip_atomic_store(&arrive[tile_id], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const bool trimmed = __syncthreads_or(got & kArriveTrimmed) != 0;
-    if (trimmed) {  // (block-uniform, rare: a block in or beside a pile) the ranges the table refers to
-      const int* tbT = tileBounds + kTbStride * tile_id;
-      const U4 lo = G<true>::ld16(tbT, 0), hi = G<true>::ld16(tbT, 16);
-      tb0 = (int)lo.x; tb1 = (int)lo.y; tb2 = (int)lo.z; tb3 = (int)lo.w; tb4 = (int)hi.x; tb5 = (int)hi.y;
-    }
-    // What pass A wrote for this block and its ranges is read with PLAIN loads from here on: every 128-byte line of the
-    // table rows, of P and of the normals is written whole by ONE block (256 particles' share of each array is a multiple
-    // of 128 bytes) and read by nobody before that block has arrived, so no cache of this CU or XCD can hold an older
-    // copy from this launch (and none from before it: caches start a launch invalidated); the producers stored
-    // write-through.  The words that share lines between blocks -- the arrival words, tileBoundsT -- are read sc1.
-    row = rows[ic];
-  }
-  const int Craw = (int)row.w[kRowCount];
   SC_STAMP_B(1);
   const int m = min(kTileW, n - i0);
   const bool live = t < m;
@@ -1317,7 +1134,7 @@ __device__ __forceinline__ void
   // registers); a block inside one gigantic bucket reads indices from the 32-bit table instead
   const auto entry16 = [&](int s) -> int { return row_entry(row, s); };
   const bool wide = total > kSlotMax;
-  const auto entry_any = [&](int s) -> int { return wide ? G<SYNC>::ld4(&nbr[(size_t)s * cap + ic]) : row_entry(row, s); };
+  const auto entry_any = [&](int s) -> int { return wide ? nbr[(size_t)s * cap + ic] : row_entry(row, s); };
   SC_STAMP_VALUE_B(10, total);
   SC_STAMP_VALUE_B(11, tile_id);
   const bool ghost = w.slab && (cpacked & kGhostBit);
@@ -1389,7 +1206,7 @@ __device__ __forceinline__ void
   double xi = 0, yi = 0, Pi = 0;  // the particle's start-of-tick position and its pressure
   if (in_lds) {
     PairSums ps{0, 0, 0, 0};
-    if (active) ps = pass_b_pairs<NOISE, true, MON, SYNC>(w, tl, txy, tss, tP, self, Cn, idi, entry16, sxy, eta, offById, P, snn, xi, yi, Pi);
+    if (active) ps = pass_b_pairs<NOISE, true, MON>(w, tl, txy, tss, tP, self, Cn, idi, entry16, sxy, eta, offById, P, snn, xi, yi, Pi);
     SC_STAMP_B(3);
     __syncthreads();  // everybody is done with (x, y): the array now takes the velocities
 #pragma unroll
@@ -1405,7 +1222,7 @@ __device__ __forceinline__ void
     }
   } else if (active) {
     idn = idi;
-    const PairSums ps = pass_b_pairs<NOISE, false, MON, SYNC>(w, tl, txy, tss, tP, self, Cn, idi, entry_any, sxy, eta, offById, P, snn, xi, yi, Pi);
+    const PairSums ps = pass_b_pairs<NOISE, false, MON>(w, tl, txy, tss, tP, self, Cn, idi, entry_any, sxy, eta, offById, P, snn, xi, yi, Pi);
     pass_b_finish<false, MON>(w, tl, txy, C, Cn, ws, entry_any, svv, wrec, ps, xi, yi, Pi, vx0, vy0, xn, yn, vxn, vyn, mon, near_now);
   }
   SC_STAMP_B(5);
@@ -1466,98 +1283,6 @@ __device__ __forceinline__ void
       }
     }
   }
-}
-
-template <int NOISE, bool FUSED, bool MON = false, bool GROUP = false, bool BANDED = false>
-__global__ void __launch_bounds__(kTileW)
-    k_pass_b(World w, int* __restrict__ counters, const XY* __restrict__ sxy, const XY* __restrict__ svv,
-             const int* __restrict__ id,
-             const int* __restrict__ wslot, const int* __restrict__ cell, const int* __restrict__ nbr,
-             const NbrRow* __restrict__ rows, int cap, const double* __restrict__ eta,
-             const int* __restrict__ offById, const double* __restrict__ P, const XY* __restrict__ snn,
-             const double* __restrict__ wrec, double* __restrict__ xo,
-             double* __restrict__ yo, double* __restrict__ vxo, double* __restrict__ vyo, int* __restrict__ ido,
-             const int* __restrict__ tileBounds, volatile int* __restrict__ progress,
-             WallInputs wn, int* __restrict__ cellS, int* __restrict__ wslotS, int* __restrict__ cellCount,
-             double* __restrict__ wrec_next, double* __restrict__ haloL,
-             double* __restrict__ haloR, int haloCap, double* __restrict__ monitor, const int* __restrict__ tileBand,
-             int part, int bandw, int epoch) {
-  __shared__ PassBLds lds;
-  SC_TIMELINE_KERNEL((w.tick & 1) ? 6 : 1);
-  pass_b_block<NOISE, FUSED, MON, GROUP, BANDED, false>(w, counters, sxy, svv, id, wslot, cell, nbr, rows, cap, eta, offById, P, snn, wrec, xo, yo,
-                                                        vxo, vyo, ido, tileBounds, progress, wn, cellS, wslotS, cellCount, wrec_next, haloL,
-                                                        haloR, haloCap, monitor, tileBand, part, bandw, epoch, lds, blockIdx.x, gridDim.x,
-                                                        nullptr, nullptr);
-}
-
-// ------------------------------------------------------------------------------------------
-// Pass A and pass B of a tick in ONE launch: the first `gridA` workgroups are pass A's blocks, the others pass B's.  The
-// dispatcher starts workgroups in index order, so pass B's first blocks take the slots that pass A's last round leaves
-// behind -- pass A ends on a chip that drains for a workgroup's life (a quarter of its span at a million particles) and
-// pass B's blocks, which wait on memory for half of theirs, fill it -- and the kernel boundary between the two is gone.
-// A block of pass B needs what pass A wrote for the tiles in its three ranges: those blocks have all been STARTED before it
-// (lower indices); it waits for their arrivals (bounded: F_AB_TIMEOUT).  The data crosses CUs and XCDs inside the launch:
-// see G<SYNC>.  Both roles keep their own register and LDS needs; the launch gets the larger of each.
-// ------------------------------------------------------------------------------------------
-template <int CAP>
-union PassAbLds {
-  PassALds<CAP> a;
-  PassBLds b;
-};
-
-template <int NOISE, int CAP, bool GROUP>
-__global__ void __launch_bounds__(kTileW)
-    k_pass_ab(World w, int* __restrict__ counters, const XY* __restrict__ sxy, const XY* __restrict__ svv,
-              const int* __restrict__ id, const int* __restrict__ wslot, const int* __restrict__ cell, Buckets bk,
-              int* __restrict__ nbr, NbrRow* __restrict__ rows, int cap, double* __restrict__ P, XY* __restrict__ snn,
-              const int* __restrict__ tileBounds, int* __restrict__ tileBand, int* __restrict__ tileBoundsT,
-              const double* __restrict__ wrec, double* __restrict__ xo, double* __restrict__ yo, double* __restrict__ vxo,
-              double* __restrict__ vyo, int* __restrict__ ido, volatile int* __restrict__ progress, WallInputs wn,
-              int* __restrict__ cellS, int* __restrict__ wslotS, int* __restrict__ cellCount, double* __restrict__ wrec_next,
-              double* __restrict__ haloL, double* __restrict__ haloR, int haloCap, int* __restrict__ arrive, int gridA) {
-  __shared__ PassAbLds<CAP> lds;
-  if ((int)blockIdx.x < gridA) {
-    SC_TIMELINE_KERNEL((w.tick & 1) ? 5 : 0);  // (diagnostic build: odd ticks in the sorting kernel's slot, so that the run's last tick -- two launches -- keeps the pair before it)
-    pass_a_block<NOISE, true, true, CAP, false, true>(w, counters, sxy, id, cell, bk, nbr, rows, cap, nullptr, nullptr, P, snn, tileBounds,
-                                                      tileBand, tileBoundsT, lds.a, blockIdx.x, gridA, arrive);
-  } else {
-    SC_TIMELINE_KERNEL((w.tick & 1) ? 6 : 1);
-    pass_b_block<NOISE, true, false, GROUP, false, true>(w, counters, sxy, svv, id, wslot, cell, nbr, rows, cap, nullptr, nullptr, P, snn,
-                                                         wrec, xo, yo, vxo, vyo, ido, tileBoundsT, progress, wn, cellS, wslotS, cellCount,
-                                                         wrec_next, haloL, haloR, haloCap, nullptr, tileBand, 0, 0, 0, lds.b,
-                                                         (int)blockIdx.x - gridA, (int)gridDim.x - gridA, tileBounds, arrive);
-  }
-}
-
-// The same hand-off between TWO launches of one stream (an experiment: hipExtAnyOrderLaunch lets the second launch's
-// workgroups start while the first one's are still running, each launch with its own registers and LDS).
-template <int NOISE, int CAP>
-__global__ void __launch_bounds__(kTileW)
-    k_pass_a_sync(World w, const int* __restrict__ counters, const XY* __restrict__ sxy, const int* __restrict__ id,
-                  const int* __restrict__ cell, Buckets bk, int* __restrict__ nbr, NbrRow* __restrict__ rows, int cap,
-                  double* __restrict__ P, XY* __restrict__ snn, const int* __restrict__ tileBounds, int* __restrict__ tileBand,
-                  int* __restrict__ tileBoundsT, int* __restrict__ arrive) {
-  __shared__ PassALds<CAP> lds;
-  SC_TIMELINE_KERNEL((w.tick & 1) ? 5 : 0);
-  pass_a_block<NOISE, true, true, CAP, false, true>(w, counters, sxy, id, cell, bk, nbr, rows, cap, nullptr, nullptr, P, snn, tileBounds,
-                                                    tileBand, tileBoundsT, lds, blockIdx.x, gridDim.x, arrive);
-}
-template <int NOISE>
-__global__ void __launch_bounds__(kTileW)
-    k_pass_b_sync(World w, int* __restrict__ counters, const XY* __restrict__ sxy, const XY* __restrict__ svv,
-                  const int* __restrict__ id, const int* __restrict__ wslot, const int* __restrict__ cell,
-                  const int* __restrict__ nbr, const NbrRow* __restrict__ rows, int cap, const double* __restrict__ P,
-                  const XY* __restrict__ snn, const int* __restrict__ tileBounds, const int* __restrict__ tileBoundsT,
-                  const double* __restrict__ wrec, double* __restrict__ xo, double* __restrict__ yo, double* __restrict__ vxo,
-                  double* __restrict__ vyo, int* __restrict__ ido, volatile int* __restrict__ progress, WallInputs wn,
-                  int* __restrict__ cellS, int* __restrict__ wslotS, int* __restrict__ cellCount, double* __restrict__ wrec_next,
-                  double* __restrict__ haloL, double* __restrict__ haloR, int haloCap, int* __restrict__ arrive) {
-  __shared__ PassBLds lds;
-  SC_TIMELINE_KERNEL((w.tick & 1) ? 6 : 1);
-  pass_b_block<NOISE, true, false, false, false, true>(w, counters, sxy, svv, id, wslot, cell, nbr, rows, cap, nullptr, nullptr, P, snn,
-                                                       wrec, xo, yo, vxo, vyo, ido, tileBoundsT, progress, wn, cellS, wslotS, cellCount,
-                                                       wrec_next, haloL, haloR, haloCap, nullptr, nullptr, 0, 0, 0, lds, blockIdx.x,
-                                                       gridDim.x, tileBounds, arrive);
 }
 
 // The side stream's wait for the window blocks of a part-3 force kernel (hipStreamWaitValue32 is not usable on this

@@ -303,14 +303,21 @@ class SlabCrate:
         ids = np.flatnonzero(own).astype(np.int64)
         n_own = int(own.sum())
         rows = max(1.0, 1.0 / d)
-        expect_halo = HALO_COLUMNS * rows * (len(p) / max(rows * rows, 1.0))
+        # what the world may hold: the initial particles, or -- with sources -- whatever they may still add up to
+        # max_particles (crate.py:142; `Crate` sizes its context the same way), so that a scene that starts empty
+        # does not run out of room or of halo records mid-run
+        expected = len(p)
+        if self.particle_sources:
+            expected = max(expected, int(world_config.coefficients.get("max_particles", 0)))
+        expect_halo = HALO_COLUMNS * rows * (expected / max(rows * rows, 1.0))
         if halo_capacity is None:
             halo_capacity = int(3.0 * expect_halo) + 4096
         if capacity is None:
-            capacity = int(1.15 * len(p) / self.world) + 4 * halo_capacity + 1024
+            capacity = int(1.15 * expected / self.world) + 4 * halo_capacity + 1024
             capacity = max(capacity, n_own + 4 * halo_capacity + 1024)
         self.left = self.rank - 1 if self.rank > 0 else None
         self.right = self.rank + 1 if self.rank < self.world - 1 else None
+        self.capacity = int(capacity)
         self.backend = backend if backend is not None else HipSlabBackend(capacity, halo_capacity, device, noise, noise_seed)
         if axis == "y" or hasattr(self.backend, "set_axis"):
             self.backend.set_axis(1 if axis == "y" else 0)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ (shader) counters of every kernel of the tick, per launch: instruction counts, VALU / LDS busy time, waits.
 # Separate --pmc passes (8 SQ slots per pass; GRBM in its own), --kernel-trace only.
-# Run on the MI355X box from the repository root:  scripts/collect_sq.sh [particles]  -> profiles/r03_sq_<N>.json
+# Run on the MI355X box from the repository root:  scripts/collect_sq.sh [particles]  -> profiles/$SC_PROFILE_TAG_sq_<N>.json (default tag r04)
 export TMPDIR=/tmp
 N=${1:-1048576}
 OUT=gpurun_out/sq

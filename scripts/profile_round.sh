@@ -4,7 +4,8 @@
 # bench line, rocprofv3 kernel stats of the same command, fabric traffic (PMC), SQ counters.  Outputs land in
 # gpurun_out/<tag>_*; copy what is to be judged into profiles/.
 export TMPDIR=/tmp
-TAG=${1:-r03}
+TAG=${1:-r04}
+export SC_PROFILE_TAG=$TAG
 N=${2:-1048576}
 mkdir -p gpurun_out
 python bench.py --particles $N > gpurun_out/${TAG}_bench_$N.json 2> gpurun_out/${TAG}_bench_$N.err || tail -5 gpurun_out/${TAG}_bench_$N.err

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Turns the counter CSVs of scripts/collect_sq.sh into profiles/r03_sq_<N>.json: per kernel, the average of every
+"""Turns the counter CSVs of scripts/collect_sq.sh into profiles/rNN_sq_<N>.json: per kernel, the average of every
 counter per launch (summed over the chip, as rocprofv3 reports it)."""
 import collections
 import csv
 import glob
-import json
+import json, os
 import sys
 
 out_dir, n = sys.argv[1], int(sys.argv[2])
@@ -32,7 +32,7 @@ res = {"particles": n, "instantiations": {name: k for name, (k, _) in picked.ite
        "source": "rocprofv3 --kernel-trace --pmc <4 SQ counters per pass>, bench.py --steps 20 --warmup 5 --repeats 1; "
                  "average per launch, summed over the chip; SQ_ACTIVE_* / SQ_WAVE_CYCLES / SQ_WAIT_* in quad-cycles",
        "kernels": {k: {c: agg[k][c] / cnt[k][c] for c in sorted(agg[k])} for k in sorted(agg)}}
-path = f"profiles/r03_sq_{n}.json"
+path = f"profiles/{os.environ.get('SC_PROFILE_TAG', 'r04')}_sq_{n}.json"
 json.dump(res, open(path, "w"), indent=1)
 for k, v in res["kernels"].items():
     if "SQ_INSTS_VALU" not in v:

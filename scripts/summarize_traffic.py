@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Turns the counter CSVs of scripts/collect_traffic.sh into profiles/r03_traffic_<N>.json:
+"""Turns the counter CSVs of scripts/collect_traffic.sh into profiles/rNN_traffic_<N>.json:
 per kernel, average FETCH_SIZE / WRITE_SIZE per launch in bytes, raw and calibrated."""
 import collections
 import csv
 import glob
-import json
+import json, os
 import sys
 
 out_dir, n = sys.argv[1], int(sys.argv[2])
@@ -51,7 +51,7 @@ for name, k in sorted(best.items()):
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
     res["kernels"][name] = {"fetch_bytes_raw": f, "write_bytes_raw": w, "fetch_bytes": f * kf, "write_bytes": w * kw,
                             "traffic_bytes": f * kf + w * kw, "traffic_bytes_per_particle": (f * kf + w * kw) / n}
-path = f"profiles/r03_traffic_{n}.json"
+path = f"profiles/{os.environ.get('SC_PROFILE_TAG', 'r04')}_traffic_{n}.json"
 json.dump(res, open(path, "w"), indent=1)
 print(json.dumps(res["calibration"]))
 for k, v in res["kernels"].items():
