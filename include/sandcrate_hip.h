@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 4
+#define SC_ABI_VERSION 5
 #define SC_MAX_NEIGHBORS 20 /* collision_detector.py:6  MAX_ALLOWED_NEIGHBORS */
 #define SC_MAX_SEGMENTS 16  /* wall segments of all rigid bodies together (scenes use 6 and 8) */
 #define SC_MAX_BODIES 8
@@ -156,6 +156,12 @@ typedef struct sc_tick_inputs {
 } sc_tick_inputs;
 int sc_tick(sc_ctx* ctx, const sc_tick_inputs* now, const sc_tick_inputs* next);
 int sc_synchronize(sc_ctx* ctx);
+
+/* The bucket scan is one pass with decoupled look-back: a workgroup waits for the totals of the workgroups before it,
+ * which the dispatcher starts first.  The wait is bounded -- `polls` attempts per predecessor (default 2^22; negative:
+ * give up at once, for tests) -- and a workgroup that gives up abandons the TICK: its later kernels do nothing, the particles
+ * stay as the tick found them, and the next synchronising call returns SC_ERR_HIP.  (A knob for tests of that path.) */
+int sc_set_scan_patience(sc_ctx* ctx, int64_t polls);
 
 /* Parity taps, valid between sc_step_begin and sc_step_finish.  Synchronise.  All arrays have one
  * entry per sorted slot k = 0..P-1 (the order of collision_detector.py:127):

@@ -82,6 +82,7 @@ SIGNATURES = {
     "sc_step": (C.c_int, [_P, C.c_int32]),
     "sc_tick": (C.c_int, [_P, C.POINTER(TickInputs), C.POINTER(TickInputs)]),
     "sc_synchronize": (C.c_int, [_P]),
+    "sc_set_scan_patience": (C.c_int, [_P, C.c_int64]),
     "sc_download_sort": (C.c_int, [_P, _I64, _I64, C.c_int64, _I64]),
     "sc_download_neighbors": (C.c_int, [_P, _I64, _I32, _I64, _D, C.c_int64, _I64]),
     "sc_download_normals": (C.c_int, [_P, _D, C.c_int64, _I64]),

@@ -9,9 +9,10 @@ name, ``editable_coefficients()``, ``debug_arrows``, ``debug_prints``, ``tick``,
 
 What runs where
 ---------------
-host   rigid-body motion (rigid_body.py) and pad_segments: O(S) per tick.  (The particle sources draw on the device --
-       sc_emit_particles, below; particle_source.py's host path remains for noise="host-sync", which also keeps the
-       global NumPy RNG stream on the host.)
+host   rigid-body motion (rigid_body.py) and pad_segments: O(S) per tick.  The particle sources: on the DEVICE
+       (sc_emit_particles, below) with noise="host", where the device holds NumPy's stream; on the host
+       (particle_source.py: `_create_new_particles`) in the modes that leave ``np.random`` to the host --
+       "counter", "none" and "host-sync".
 GPU    everything per particle: removal, wall contacts + hard wall fix, strip sort and neighbor
        lists, pressure / tension / gravity / viscosity / wall bounce / continuous collision,
        integration (sand_crate_amd/csrc/sc_kernels.h).  State stays on the device; the

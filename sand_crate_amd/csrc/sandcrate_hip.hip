@@ -6,6 +6,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -93,6 +94,7 @@ struct sc_ctx {
   int *cellCount = nullptr, *cellStart = nullptr, *sortedStamp = nullptr;
   unsigned long long* scanDesc = nullptr;  // the bucket scan's look-back descriptors, one per 2048 cells (k_scan_cells)
   unsigned scanStamp = 0;                  // ... and the stamp of its last launch
+  int scan_max_polls = kScanMaxPolls;      // ... and how often a workgroup asks for a predecessor's total before it gives up (sc_set_scan_patience)
   int2* sortTasks = nullptr;  // k_sort_big's task list (cell, chunk | length): the scan writes it
   RcclComm comm = nullptr;  // RCCL communicator of the slab chain (sc_comm_init), or null
   int comm_rank = -1, comm_world = 0;
@@ -414,7 +416,8 @@ int check_flags(int flags) {
   if (flags & F_BAND_TIMEOUT)
     return fail(SC_ERR_HIP, "the halo exchange waited 50 ms for the band blocks of the force kernel and gave up");
   if (flags & F_SCAN_TIMEOUT)
-    return fail(SC_ERR_HIP, "the bucket scan waited for a workgroup that never published its total and gave up");
+    return fail(SC_ERR_HIP, "the bucket scan waited for a workgroup that never published its total and gave up; the tick was "
+                "skipped (the particles are as the tick found them)");
   if (flags & F_HALO_LATE)
     return fail(SC_ERR_DOMAIN, "a particle moved more than the band margin (%d columns / %d rows) in one tick and missed the "
                 "overlapped halo message: run without halo overlap", kBandMarginColumns, kBandMarginRows);
@@ -711,8 +714,20 @@ int sc_synchronize(sc_ctx* c) {
   if (!c->in_step) c->upper = h[C_NS];
   if (h[C_FLAGS]) {
     HIPCHK(hipMemsetAsync(c->counters + C_FLAGS, 0, sizeof(int), c->stream));
+    if (h[C_FLAGS] & F_SCAN_TIMEOUT) {
+      // the tick was abandoned behind its scan: its bucket counts were never consumed, and whatever a look-ahead
+      // promised for the tick after it was never computed -- the next tick starts from the storage arrays
+      HIPCHK(hipMemsetAsync(c->cellCount, 0, c->cellAlloc * sizeof(int), c->stream));
+      c->prebinned = false;
+    }
     return check_flags(h[C_FLAGS]);
   }
+  return SC_OK;
+}
+
+int sc_set_scan_patience(sc_ctx* c, int64_t polls) {
+  if (!c) return fail(SC_ERR_ARG, "null context");
+  c->scan_max_polls = polls < 0 ? -1 : (int)std::min<int64_t>(polls, kScanMaxPolls);
   return SC_OK;
 }
 
@@ -809,7 +824,7 @@ int sc_step_begin(sc_ctx* c) {
     const int nb = (int)((ncells + 1 + kScanPerBlock - 1) / kScanPerBlock);  // covers the one-past-the-end entry
     c->scanStamp = c->scanStamp % 0x3FFFFFFFu + 1;  // 1 .. 2^30 - 1: never the cleared descriptors' 0
     hipLaunchKernelGGL(k_scan_cells, dim3(nb), dim3(kBlock), 0, c->stream, c->cellCount, c->cellStart, (int)ncells,
-                       c->scanDesc, c->scanStamp, c->counters, c->sortTasks);
+                       c->scanDesc, c->scanStamp, c->counters, c->sortTasks, c->scan_max_polls);
   }
   {
     Bracket br(c, K_SCATTER);
@@ -1778,7 +1793,11 @@ int sc_emit_particles(sc_ctx* c, const sc_source* sources, int32_t n_sources, do
   }
   // host-side bounds of the stored count and of the ids: at most `bound` particles per source; the live count a
   // recent tick published (progress block) keeps the bound from drifting away without any synchronisation
-  const int64_t done = *(volatile int*)(c->bigHintHost + 1), live = *(volatile int*)(c->bigHintHost + 2);
+  // (the device writes the tick number last: the three words belong together when it reads the same before and after)
+  int64_t done = *(volatile int*)(c->bigHintHost + 1);
+  const int64_t live = *(volatile int*)(c->bigHintHost + 2), published_ids = *(volatile int*)(c->bigHintHost + 3);
+  std::atomic_thread_fence(std::memory_order_acquire);
+  if (*(volatile int*)(c->bigHintHost + 1) != done) done = -1;  // a tick finished in between: no hint this time
   int64_t upper = c->upper + most;
   if (done > c->live_hint_from && c->tick >= done && c->tick - done <= 8)
     upper = std::min(upper, live + (c->tick - done + 1) * most);
@@ -1795,7 +1814,6 @@ int sc_emit_particles(sc_ctx* c, const sc_source* sources, int32_t n_sources, do
   // it every tick.  The count the device published with a recent tick pulls it back, like `upper` above.
   c->emit_most = std::max(c->emit_most, most);
   if (done > c->live_hint_from && c->tick >= done && c->tick - done <= 8) {
-    const int64_t published_ids = *(volatile int*)(c->bigHintHost + 3);
     if (published_ids > 0) c->next_id = std::min(c->next_id, published_ids + (c->tick - done + 1) * c->emit_most);
   }
   if (c->next_id + most > std::numeric_limits<int>::max()) return fail(SC_ERR_CAPACITY, "particle ids exhausted");

@@ -301,7 +301,10 @@ __global__ void __launch_bounds__(kBlock) k_scan_fix(int* __restrict__ out, int 
 // the block and block offsets that the last workgroup to draw a ticket scanned alone on the GPU: a returning atomic, a
 // fence and two more round trips on the critical path of a 7.5 us kernel, and a second load in every bucket lookup.)
 // The stamp changes with every launch, so the descriptors are never cleared.  A workgroup waits for lower block indices
-// only, which the dispatcher starts first; the wait is bounded all the same (F_SCAN_TIMEOUT).
+// only, which the dispatcher starts first; the wait is bounded all the same (`max_polls`: sc_set_scan_patience).  A
+// workgroup that gives up raises F_SCAN_TIMEOUT -- and with that flag up every later kernel of the tick returns at its
+// first instruction (tick_abandoned): the bucket starts are not to be trusted, so the tick is SKIPPED, the storage
+// arrays keep the state the tick started from, and the error reaches the caller with that state intact.
 constexpr int kSortThreshold = 96;  // buckets above this many particles are listed for k_sort_big
 #ifndef SC_SORT_BLOCK
 #define SC_SORT_BLOCK 512
@@ -335,6 +338,11 @@ struct alignas(16) SortKey {
   int src;
 };
 
+// A tick whose bucket scan gave up is abandoned: its later kernels do nothing (k_scan_cells).
+__device__ __forceinline__ bool tick_abandoned(const int* __restrict__ counters) {
+  return (__hip_atomic_load(&counters[C_FLAGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & F_SCAN_TIMEOUT) != 0;
+}
+
 struct Buckets {
   const int* __restrict__ start;
   __device__ __forceinline__ int operator()(int c) const { return start[c]; }
@@ -348,7 +356,7 @@ __device__ __forceinline__ unsigned long long scan_desc(unsigned stamp, unsigned
 
 __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ in, int* __restrict__ out, int n,
                                                        unsigned long long* __restrict__ desc, unsigned stamp,
-                                                       int* __restrict__ counters, int2* __restrict__ sortTasks) {
+                                                       int* __restrict__ counters, int2* __restrict__ sortTasks, int max_polls) {
   SC_TIMELINE_SCAN();
   __shared__ int waveTot[kBlock / 64], waveTasks[kBlock / 64], waveBig[kBlock / 64];
   __shared__ int blockBase, taskBase;
@@ -411,7 +419,8 @@ __global__ void __launch_bounds__(kBlock) k_scan_cells(const int* __restrict__ i
           late = (unsigned)(d >> 34) != stamp;
           if (__ballot(late) == 0) break;
           __builtin_amdgcn_s_sleep(2);
-        } while (++polls < kScanMaxPolls);
+        } while (++polls < max_polls);
+        if (max_polls < 0) late = true;  // (sc_set_scan_patience(-1), for tests: give up without having looked)
         if (__ballot(late)) {  // never seen: a predecessor that was not started -- give up loudly instead of hanging
           if (lane == 0) atomicOr(&counters[C_FLAGS], F_SCAN_TIMEOUT);
           break;
@@ -485,6 +494,7 @@ __global__ void __launch_bounds__(kSortBlock) SC_SORT_WAVES_ATTR
   __shared__ int waveTot[kSortBins / 64];
   static_assert(kSortBins == 256 && kSortBlock >= kSortBins && kSortChunk % kSortBlock == 0, "the first 256 threads hold one sample / one bin each");
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tick_abandoned(counters)) return;
   const int total = min(__hip_atomic_load(&counters[C_NTASKS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), kMaxSortTasks);
   for (int task = blockIdx.x; task < total; task += gridDim.x) {
     const int2 tk = sortTasks[task];  // the scan's list: (cell, chunk of its bucket | length of the chunk - 1)
@@ -696,7 +706,7 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ coun
   const double xi = xS[ic];
   const int idi = idS[ic];
   SC_STAMP(4, 0);
-  if (i >= counters[C_NS]) c = -1;
+  if (i >= counters[C_NS] || tick_abandoned(counters)) c = -1;  // (an abandoned tick scatters nothing: every lane stays idle)
   if (c >= 0) c &= kCellMask;
   SC_STAMP(4, 1);
   const int lane = threadIdx.x & 63;
@@ -781,7 +791,7 @@ __global__ void __launch_bounds__(kReorderBlock)
   const int s = chunk_of_block(live_hint) * blockDim.x + threadIdx.x;
   SC_STAMP(5, 0);
   const int nlive = counters[C_NT];
-  if (s - (int)threadIdx.x >= nlive) return;  // a block beyond the live particles (a slab's grid covers its capacity)
+  if (s - (int)threadIdx.x >= nlive || tick_abandoned(counters)) return;  // a block beyond the live particles (a slab's grid covers its capacity)
   const bool live = s < nlive;
   int i = 0, idi = 0, cpacked = 0, c = 0, wsi = 0, b = 0, e = 0;
   double xi = 0, yi = 0, vxi = 0, vyi = 0;

@@ -690,7 +690,7 @@ __global__ void __launch_bounds__(kTileW)
   const int* tb = tileBounds + 6 * tile_id;
   const int tb0 = tb[0], tb1 = tb[1], tb2 = tb[2], tb3 = tb[3], tb4 = tb[4], tb5 = tb[5];
   const int n = counters[C_NT];
-  if (i0 >= n) return;
+  if (i0 >= n || tick_abandoned(counters)) return;
   const int m = min(kTileW, n - i0);
   const bool live = t < m;
 
@@ -1072,6 +1072,7 @@ __global__ void __launch_bounds__(kTileW)
   const int ws_raw = wslot[ic];
   const int idi = id[ic];
   const int n = counters[C_NT];
+  if (tick_abandoned(counters)) return;  // (before anything is written: the storage arrays keep the state the tick started from)
   if (tile_id == 0 && t == 0 && part != 2) {
     counters[C_NS] = n;    // the storage arrays now hold the n live particles
     counters[C_SUMC] = 0;  // per-tick counters start the next tick at zero (sc_step_stats reads them
@@ -1081,9 +1082,13 @@ __global__ void __launch_bounds__(kTileW)
     counters[C_NBIG] = 0;
     counters[C_NTASKS] = 0;
     SC_TIMELINE_EPOCH(w.tick + 1);
-    progress[1] = w.tick + 1;  // host-mapped: the host keeps at most a few ticks of launches queued
-    progress[2] = n;           // ... and sizes heuristics by a recent live count
-    progress[3] = counters[C_NEXT_ID];  // ... and keeps its bound of the ids handed out near the device's count (sc_emit_particles)
+    // host-mapped: the host keeps at most a few ticks of launches queued (progress[1]), sizes heuristics by a recent live
+    // count ([2]) and keeps its bound of the ids handed out near the device's count ([3]: sc_emit_particles).  The tick
+    // number goes LAST, behind a release: a reader that sees the same tick before and after reading [2] and [3] has
+    // that tick's values
+    progress[2] = n;
+    progress[3] = counters[C_NEXT_ID];
+    __hip_atomic_store(const_cast<int*>(&progress[1]), w.tick + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (BANDED && part == 3 && n == 0 && blockIdx.x == 0 && t == 0)  // nothing at all: nobody else would publish the epoch
     __hip_atomic_store(&counters[C_BAND_FLAG], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

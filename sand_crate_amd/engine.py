@@ -193,6 +193,11 @@ class Engine:
     def synchronize(self) -> None:
         N.check(self._lib.sc_synchronize(self._ctx))
 
+    def set_scan_patience(self, polls: int) -> None:
+        """How often a workgroup of the bucket scan asks for a predecessor's total before the tick is abandoned
+        (sc_set_scan_patience; negative: at once -- the path's test)."""
+        N.check(self._lib.sc_set_scan_patience(self._ctx, int(polls)))
+
     # -- parity taps (between step_begin and step_finish)
     def download_sort(self):
         room = self.capacity

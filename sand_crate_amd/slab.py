@@ -135,6 +135,33 @@ def draw_new_particles(sources, tick: int, dt: float, max_particles: int, count:
     return out
 
 
+def draw_with_count_bound(sources, tick: int, dt: float, max_particles: int, bound: int, exact_count):
+    """The same draws WITHOUT counting the particles first, whenever the count cannot matter: the reference takes
+    min(binomial, max_particles - count) (crate.py:142), so with an upper bound of the count in its place a draw that
+    stays below the room it was given is the reference's draw.  Only when some source filled its room does the exact count
+    decide: the stream is rewound and the draw repeated with `exact_count()` (one synchronisation and, across ranks, one
+    all-reduce -- per emitting tick before this, now only near max_particles).  -> (draws, count bound after them)"""
+    state = np.random.get_state()
+    count, binding = bound, False
+    out = []
+    for source in sources:
+        if source.active_ticks <= tick:
+            continue
+        room = max_particles - count
+        new_p, new_v = source.generate_particles(dt=dt, max_particles=room)
+        n = 0 if new_p is None else len(new_p)
+        binding |= n >= room
+        if new_p is not None:
+            out.append((new_p, new_v))
+            count += n
+    if not binding:
+        return out, count
+    np.random.set_state(state)
+    exact = int(exact_count())
+    out = draw_new_particles(sources, tick, dt, max_particles, exact)
+    return out, exact + sum(len(p) for p, _ in out)
+
+
 class HipSlabBackend:
     """The compute side of one slab on one GPU: an `Engine` in slab mode plus halo buffers held as
     torch tensors (device memory and stream plumbing only)."""
@@ -324,6 +351,7 @@ class SlabCrate:
         self.backend.set_slab(self.lo, self.hi, HALO_COLUMNS, self.left is not None, self.right is not None)
         self._own_mask = own
         self._next_id = len(p)  # ids are global: every rank numbers the emitted particles alike
+        self._count_bound = len(p)  # an upper bound of the global particle count (removals are not counted): `_emit`
         if self.particle_sources and not self._chained:
             np.random.seed(0)   # crate.py:22 (a chain seeds once, for all its members)
         self.backend.load(p[own], v[own], ids)
@@ -624,8 +652,9 @@ class SlabCrate:
         if not self._sources_active(self.tick):
             return
         if drawn is None:
-            drawn = draw_new_particles(self.particle_sources, self.tick, self.dt, int(self.max_particles),
-                                       self.global_particle_count())
+            # (the count only matters near max_particles: `_count_bound`, what was loaded plus everything emitted since)
+            drawn, self._count_bound = draw_with_count_bound(self.particle_sources, self.tick, self.dt, int(self.max_particles),
+                                                             self._count_bound, self.global_particle_count)
         d = self.particle_radius * 2
         for new_p, new_v in drawn:
             ids = self._next_id + np.arange(len(new_p), dtype=np.int64)
@@ -743,8 +772,9 @@ class SlabChain:
             for m in ms:
                 m._begin_tick()
             if ms[0]._sources_active(ms[0].tick):  # one draw for all members (they share this process's np.random)
-                drawn = draw_new_particles(ms[0].particle_sources, ms[0].tick, ms[0].dt, int(ms[0].max_particles),
-                                           sum(self.owned_counts()))
+                drawn, ms[0]._count_bound = draw_with_count_bound(ms[0].particle_sources, ms[0].tick, ms[0].dt,
+                                                                  int(ms[0].max_particles), ms[0]._count_bound,
+                                                                  lambda: sum(self.owned_counts()))
                 for m in ms:
                     m._emit(drawn)
             changed = False

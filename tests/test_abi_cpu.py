@@ -42,7 +42,7 @@ def test_ctypes_table_matches_header():
 
 def test_abi_version_and_error_string(lib):
     lib.sc_abi_version.restype = ctypes.c_int
-    assert lib.sc_abi_version() == 4
+    assert lib.sc_abi_version() == 5
     lib.sc_last_error.restype = ctypes.c_char_p
     assert isinstance(lib.sc_last_error(), bytes)
 

@@ -9,6 +9,8 @@ decision (post wall-fix) bit-exact; float positions / velocities / pressure with
 import itertools
 from math import ceil, floor
 
+import copy
+
 import numpy as np
 import pytest
 
@@ -569,6 +571,31 @@ def test_nan_particle_is_dropped_and_reported(sc):
         crate.synchronize()
     assert e.value.code == N.ERR_DOMAIN and "NaN" in str(e.value)
     assert crate.particle_count == 2
+
+
+def test_a_scan_that_gives_up_skips_the_tick(sc):
+    """The bucket scan's workgroups wait for the workgroups before them, bounded (sc_set_scan_patience).  One that gives
+    up abandons the tick: every later kernel returns at once, the particles stay as the tick found them -- through the
+    ticks that were queued behind it too -- and the next synchronising call says so; after that the run goes on from
+    that state."""
+    from sand_crate_amd import _native as N
+    crate, wc, p, v, d = bench_like_crate(sc, 262144)   # (a grid of 264 x 264 cells: 35 workgroups in the scan)
+    crate.run(2)
+    crate.synchronize()
+    before = crate.engine.download()
+    crate.engine.set_scan_patience(-1)                  # every workgroup but the first gives up without having looked
+    crate.run(3)
+    with pytest.raises(N.NativeError) as e:
+        crate.synchronize()
+    assert e.value.code == N.ERR_HIP and "bucket scan" in str(e.value) and "skipped" in str(e.value)
+    after = crate.engine.download()
+    for a, b in zip(before, after):
+        assert np.array_equal(a, b)
+    crate.engine.set_scan_patience(1 << 22)
+    crate.run(2)                                        # ... and the run goes on from there
+    crate.synchronize()
+    moved = crate.engine.download()
+    assert len(moved[0]) == len(p) and not np.array_equal(moved[0], before[0])
 
 
 def test_live_coefficient_edits_take_effect(sc):
