@@ -228,7 +228,8 @@ def main() -> None:
                     help="the W+K-step measurement is repeated this many times from the same initial state; `value` is the "
                          "median repetition (each repetition times exactly K steps)")
     ap.add_argument("--cpu-sample", type=int, default=262144,
-                    help="particles in the CPU baseline tick (0 = skip); 262,144 is one tick of ~13 s")
+                    help="particles in the CPU baseline tick (0 = skip); 262,144 is one tick of ~13 s.  N > 1: rank 0 times "
+                         "a quarter of it (65,536 particles, ~3 s) behind the timed region while the other ranks wait")
     ap.add_argument("--noise", default="counter", choices=["counter", "none"])
     ap.add_argument("--slab-axis", default="y", choices=["x", "y"],
                     help="N > 1: cut the domain into slabs of rows (y: the halo bands are the ends of the sorted order, the "
@@ -509,9 +510,19 @@ def main() -> None:
             line["device_flags"] = sorted(set(device_flags))
         if world == 1:
             line["regimes"] = regimes(make_sim, settle, per_gpu)
+            if per_gpu != 262144:  # BASELINE.json configs[1] heats up sooner (the tick doubles from tick ~105 on)
+                def small_sim():
+                    import copy
+                    sw, _ = world_for(262144)
+                    s_ = sc.Crate(copy.deepcopy(sw), device=local_rank, noise=args.noise, noise_seed=1, capacity=262144 + 1024)
+                    s_.particles, s_.particle_velocities = synthetic_state(262144)
+                    return s_
+                line["regimes_262144"] = regimes(small_sim, settle, 262144)
             line["drop_in_physics_tick"] = drop_in_ticks()
-        if world == 1 and args.cpu_sample > 0:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        if args.cpu_sample > 0:
+            # the reference NumPy path on this box's host cores, in the same run (N > 1: a smaller sample on rank 0, the
+            # path is flat in the particle count -- SURVEY.md section 6)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample if world == 1 else max(4096, args.cpu_sample // 4))
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist

@@ -37,6 +37,7 @@ from __future__ import annotations
 
 import copy
 import math
+import time
 import os
 
 import numpy as np
@@ -513,6 +514,8 @@ class SlabCrate:
         if ev:
             out["exchange_us_mean"] = round(1000.0 * sum(a.elapsed_time(b) for a, b in ev) / len(ev), 2)
             out["exchanges_timed"] = len(ev)
+        if getattr(self, "host_us_per_tick", None):  # of the last run(): is the rank bound by its host or by its GPU?
+            out["host_us_per_tick"] = self.host_us_per_tick
         return out
 
     def _exchange(self) -> None:
@@ -667,12 +670,20 @@ class SlabCrate:
     def run(self, n_ticks: int) -> None:
         if self._chained:
             raise RuntimeError("a chain member is stepped by its SlabChain")
+        t0 = t_head = time.perf_counter()
+        head = min(n_ticks, 4)  # (the library lets the host run four ticks ahead: these are enqueued without waiting)
         for k in range(n_ticks):
             self._begin_tick()  # (first: the count the emission needs is taken on the coming tick's grid)
             self._emit()
             self._pack(whole_messages=self._rebalance())
             self._exchange()
             self._end_tick(self._may_promise(k, n_ticks))
+            if k + 1 == head:
+                t_head = time.perf_counter()
+        # what the host spent per tick: enqueueing alone (the first ticks of the call, nothing to wait for) and over the
+        # whole call (the host waits once it is four ticks ahead of the GPU: then this is the GPU's tick)
+        self.host_us_per_tick = {"enqueue_first_ticks": round(1e6 * (t_head - t0) / max(head, 1), 1),
+                                 "whole_call": round(1e6 * (time.perf_counter() - t0) / max(n_ticks, 1), 1), "ticks": n_ticks}
 
     def physics_tick(self) -> None:
         self.run(1)

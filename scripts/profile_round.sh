@@ -12,6 +12,8 @@ python bench.py --particles $N > gpurun_out/${TAG}_bench_$N.json 2> gpurun_out/$
 rm -rf gpurun_out/${TAG}_stats_$N
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats_$N -- python bench.py --particles $N --cpu-sample 0 --no-kernel-events --repeats 1 --clock-warmup 0 > gpurun_out/${TAG}_stats_$N.log 2>&1 || tail -5 gpurun_out/${TAG}_stats_$N.log
 cp gpurun_out/${TAG}_stats_$N/*/*kernel_stats.csv gpurun_out/${TAG}_kernel_stats_$N.csv 2>/dev/null
+# the raw per-dispatch trace of the same run (~50 KB gzipped): the per-call summary below can be re-derived from it
+gzip -c gpurun_out/${TAG}_stats_$N/*/*kernel_trace.csv > gpurun_out/${TAG}_kernel_trace_$N.csv.gz 2>/dev/null
 # per-call durations of the workload's launches only (the --stats CSV averages the primer's launches in): what
 # bench.py reports as roofline.rocprof
 python scripts/summarize_trace.py gpurun_out/${TAG}_stats_$N gpurun_out/${TAG}_kernel_calls_$N.json $N > gpurun_out/${TAG}_kernel_calls_$N.log 2>&1 || tail -3 gpurun_out/${TAG}_kernel_calls_$N.log

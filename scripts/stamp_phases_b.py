@@ -28,6 +28,12 @@ for k in (1, 3):
     cols = order if fused else [0, 1, 2, 3, 4, 5, 6, 7]
     nm = names if fused else names[:5] + ["look-ahead (none)", "stores"]
     ok = (st[:, cols] > 0).all(axis=1)
+    # a slot the launch never wrote still holds an earlier launch's stamp: a wave counts only when its stamps ascend (and
+    # a buffer in which most waves do not is not a launch of this form at all -- r03's third block of negative medians)
+    ok &= (np.diff(st[:, cols], axis=1) >= 0).all(axis=1)
+    if ok.sum() < 0.5 * len(st):
+        print(f"pass B buffer {k}: {ok.sum()} of {len(st)} waves have a complete ascending set of stamps -- not a launch of this form, skipped")
+        continue
     sel = st[ok][:, cols]
     dt = np.diff(sel, axis=1)
     life = sel[:, -1] - sel[:, 0]
