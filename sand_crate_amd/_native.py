@@ -16,6 +16,8 @@ MAX_SEGMENTS = 16
 MAX_BODIES = 8
 NUM_KERNELS = 12
 NOISE_NONE, NOISE_HOST, NOISE_COUNTER = 0, 1, 2
+ERR_ARG = -1
+ERR_HIP = -2
 ERR_CAPACITY = -3
 ERR_STATE = -4
 ERR_DOMAIN = -5

@@ -25,8 +25,9 @@ stream in the reference.  Modes:
               ``np.random`` like the reference (crate.py:22) and hands the state to the library
               (sc_rng_set_state); sources and noise are then drawn by kernels (sc_rng.h) and a tick costs no
               readback, no host draw and no upload.  `sync_host_rng()` returns the stream to ``np.random``
-              for callers that draw from it themselves between ticks.  A source outside the inversion branch
-              of NumPy's legacy binomial (flow * dt > 30) makes the crate fall back to
+              for callers that draw from it themselves between ticks.  (Both branches of NumPy's legacy binomial are
+              on the device -- inversion up to flow * dt = 30, BTPE beyond; only dt > 0.5 makes the crate fall back to
+              the next mode.)
 ``"host-sync"`` the same numbers drawn by the host: one device->host count and one upload per tick;
 ``"counter"`` a counter-based hash on the device keyed by (seed, tick, particle id, slot): same
               distribution, different numbers, no host round trip (used for throughput runs);
@@ -196,13 +197,13 @@ class Crate:
             self._host_rng_mark = (key.copy(), pos)
 
     def _fall_back_to_host_stream(self) -> None:
-        """A particle source whose flow * dt exceeds 30 takes the BTPE branch of NumPy's legacy binomial
-        (particle_source.py:18), which the device does not have (sc_rng.h holds the inversion branch): from here on the
-        host draws the stream -- same numbers, but two synchronisations per tick.  Said out loud, once."""
+        """A particle source whose time step exceeds one half (binomial(n, p) with p > 0.5) is outside what the device
+        draws of NumPy's legacy binomial (sc_rng.h: inversion and BTPE for 0 < p <= 0.5): from here on the host draws the
+        stream -- same numbers, but two synchronisations per tick.  Said out loud, once."""
         import warnings
-        warnings.warn("sand_crate_amd: a particle source draws binomial(n, p) with n * p > 30 -- that branch of NumPy's legacy "
-                      "binomial is not on the device; physics_tick() falls back to noise='host-sync' (identical results, two "
-                      "host synchronisations per tick) for the rest of this run", RuntimeWarning, stacklevel=3)
+        warnings.warn("sand_crate_amd: a particle source draws binomial(n, p) with p > 0.5 -- not on the device; "
+                      "physics_tick() falls back to noise='host-sync' (identical results, two host synchronisations per "
+                      "tick) for the rest of this run", RuntimeWarning, stacklevel=3)
         self.sync_host_rng()
         self._noise = "host-sync"
 
@@ -431,7 +432,7 @@ class Crate:
                     return
                 if err.code != N.ERR_DOMAIN:
                     raise
-                self._fall_back_to_host_stream()  # binomial outside the inversion branch: the host draws from here on
+                self._fall_back_to_host_stream()  # binomial(n, p) with p > 0.5: the host draws from here on
         for source in self.particle_sources:
             if source.active_ticks <= self.tick:
                 continue

@@ -1778,9 +1778,10 @@ int sc_emit_particles(sc_ctx* c, const sc_source* sources, int32_t n_sources, do
   for (int i = 0; i < n_sources; ++i) {
     const sc_source& s = sources[i];
     const double p = dt;
-    // the legacy binomial takes this branch for p <= 0.5 and n p <= 30 (both YAML scenes: n p = 4 and 14)
-    if (!(p > 0.0 && p <= 0.5) || s.flow < 1 || (double)s.flow * p > 30.0)
-      return fail(SC_ERR_DOMAIN, "binomial(%lld, %g) is outside the inversion branch of NumPy's legacy generator",
+    // the legacy binomial for p <= 0.5: inversion up to n p = 30 (both YAML scenes: n p = 4 and 14), BTPE beyond;
+    // p > 0.5 (a time step above one half) is not on the device
+    if (!(p > 0.0 && p <= 0.5) || s.flow < 1)
+      return fail(SC_ERR_DOMAIN, "binomial(%lld, %g): the device draws NumPy's legacy binomial for 0 < p <= 0.5 only",
                   (long long)s.flow, p);
     SourceK& d = k.src[i];
     d.radius = s.radius; d.px = s.position_x; d.py = s.position_y; d.vx = s.velocity_x; d.vy = s.velocity_y;
@@ -1789,6 +1790,24 @@ int sc_emit_particles(sc_ctx* c, const sc_source* sources, int32_t n_sources, do
     d.qn = std::exp((double)s.flow * std::log(d.q));
     const double np_ = (double)s.flow * p;
     d.bound = (long long)std::min((double)s.flow, np_ + 10.0 * std::sqrt(np_ * d.q + 1));
+    d.btpe = np_ > 30.0 ? 1 : 0;
+    if (d.btpe) {  // randomkit's rk_binomial_btpe set-up, in its operation order (r = p, q = 1 - p here)
+      const double n = (double)s.flow, r = p, q = d.q, fm = n * r + r;
+      d.m = (long long)std::floor(fm);
+      d.p1 = std::floor(2.195 * std::sqrt(n * r * q) - 4.6 * q) + 0.5;
+      d.xm = (double)d.m + 0.5;
+      d.xl = d.xm - d.p1;
+      d.xr = d.xm + d.p1;
+      d.c = 0.134 + 20.5 / (15.3 + (double)d.m);
+      double a = (fm - d.xl) / (fm - d.xl * r);
+      d.laml = a * (1.0 + a / 2.0);
+      a = (d.xr - fm) / (d.xr * q);
+      d.lamr = a * (1.0 + a / 2.0);
+      d.p2 = d.p1 * (1.0 + 2.0 * d.c);
+      d.p3 = d.p2 + d.c / d.laml;
+      d.p4 = d.p3 + d.c / d.lamr;
+      d.nrq = n * r * q;
+    }
     most += d.bound;
   }
   // host-side bounds of the stored count and of the ids: at most `bound` particles per source; the live count a

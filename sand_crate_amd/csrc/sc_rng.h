@@ -1,7 +1,7 @@
 // NumPy's legacy global generator on the device: MT19937 with NumPy's state layout
 // (624-word key + position), `random_sample` doubles, and what the tick draws from it --
-//   k_rng_emit   ParticleSource.generate_particles (particle_source.py:17-24) for every active source: the
-//                inversion branch of the legacy binomial, then rand(n, 2) for the position jitter and rand(n, 2)
+//   k_rng_emit   ParticleSource.generate_particles (particle_source.py:17-24) for every active source: the legacy
+//                binomial (inversion up to flow dt = 30, BTPE beyond), then rand(n, 2) for the position jitter and rand(n, 2)
 //                for the velocity noise, appended to the storage arrays (crate.py:138-147);
 //   k_rng_noise  the tick's collider noise (crate.py:169): one block rand(sum C_i, 2), which is what the reference
 //                draws particle by particle (`rand(a, 2)` then `rand(b, 2)` is `rand(a + b, 2)` split).
@@ -62,7 +62,73 @@ struct SourceK {
   double radius, px, py, vx, vy, noise;
   double p, q, qn;          // binomial(flow, p): p = dt, q = 1 - p, qn = q^flow as exp(flow log q) (host libm, like NumPy)
   long long flow, bound;    // restart bound min(flow, flow p + 10 sqrt(flow p q + 1))
+  // flow p > 30: the BTPE branch (randomkit rk_binomial_btpe) and its constants, taken on the host like NumPy takes them
+  int btpe;
+  long long m;
+  double p1, xm, xl, xr, c, laml, lamr, p2, p3, p4, nrq;
 };
+
+// NumPy's legacy binomial for p <= 0.5 and n p > 30 (Kachitvichyanukul & Schmeiser's BTPE as randomkit has it; oracle/rng.py:
+// binomial_btpe is the same, pinned against np.random): two doubles per attempt -- a point under the triangle is accepted as
+// it is, the parallelograms and the exponential tails go through the squeeze and, near the mode, the explicit ratio.
+// (The logarithms are the device library's: a result decided differently from glibc's needs a draw within an ulp of an
+// integer boundary.)
+template <class Rng>
+__device__ long long binomial_btpe(Rng& rng, const SourceK& s) {
+  const long long n = s.flow, m = s.m;
+  const double r = s.p, q = s.q;
+  for (;;) {
+    const double u = rng.next_double() * s.p4;
+    double v = rng.next_double();
+    long long y;
+    if (u <= s.p1) return (long long)floor(s.xm - s.p1 * v + u);
+    if (u <= s.p2) {
+      const double x = s.xl + (u - s.p1) / s.c;
+      v = v * s.c + 1.0 - fabs((double)m - x + 0.5) / s.p1;
+      if (v > 1.0) continue;
+      y = (long long)floor(x);
+    } else if (u <= s.p3) {
+      if (v == 0.0) continue;
+      const double yy = floor(s.xl + log(v) / s.laml);
+      if (yy < 0.0) continue;
+      y = (long long)yy;
+      v = v * (u - s.p2) * s.laml;
+    } else {
+      if (v == 0.0) continue;
+      const double yy = floor(s.xr - log(v) / s.lamr);
+      if (yy > (double)n) continue;
+      y = (long long)yy;
+      v = v * (u - s.p3) * s.lamr;
+    }
+    const long long k = y > m ? y - m : m - y;
+    if (k > 20 && (double)k < s.nrq / 2.0 - 1) {
+      const double kd = (double)k;
+      const double rho = (kd / s.nrq) * ((kd * (kd / 3.0 + 0.625) + 0.16666666666666666) / s.nrq + 0.5);
+      const double t = -kd * kd / (2 * s.nrq);
+      const double A = log(v);
+      if (A < t - rho) return y;
+      if (A > t + rho) continue;
+      const double x1 = (double)(y + 1), f1 = (double)(m + 1), z = (double)(n + 1 - m), w = (double)(n - y + 1);
+      const double x2 = x1 * x1, f2 = f1 * f1, z2 = z * z, w2 = w * w;
+      if (A > (s.xm * log(f1 / x1) + ((double)(n - m) + 0.5) * log(z / w) + (double)(y - m) * log(w * r / (x1 * q)) +
+               (13680. - (462. - (132. - (99. - 140. / f2) / f2) / f2) / f2) / f1 / 166320. +
+               (13680. - (462. - (132. - (99. - 140. / z2) / z2) / z2) / z2) / z / 166320. +
+               (13680. - (462. - (132. - (99. - 140. / x2) / x2) / x2) / x2) / x1 / 166320. +
+               (13680. - (462. - (132. - (99. - 140. / w2) / w2) / w2) / w2) / w / 166320.))
+        continue;
+      return y;
+    }
+    const double sq = r / q, a = sq * (double)(n + 1);
+    double F = 1.0;
+    if (m < y) {
+      for (long long i = m + 1; i <= y; ++i) F *= (a / (double)i - sq);
+    } else if (m > y) {
+      for (long long i = y + 1; i <= m; ++i) F /= (a / (double)i - sq);
+    }
+    if (v > F) continue;
+    return y;
+  }
+}
 constexpr int kMaxSources = 8;
 struct SourcesK {
   SourceK src[kMaxSources];
@@ -82,18 +148,25 @@ __global__ void k_rng_emit(SourcesK srcs, long long max_particles, RngState* __r
   int next_id = counters[C_NEXT_ID];
   for (int k = 0; k < srcs.n; ++k) {
     const SourceK s = srcs.src[k];
-    // legacy random_binomial_inversion
     long long X = 0;
-    double px = s.qn, U = rng.next_double();
-    while (U > px) {
-      ++X;
-      if (X > s.bound) {
-        X = 0;
-        px = s.qn;
-        U = rng.next_double();
-      } else {
-        U -= px;
-        px = ((double)(s.flow - X + 1) * s.p * px) / ((double)X * s.q);
+    if (s.btpe) {  // legacy random_binomial_btpe (flow p > 30)
+      X = binomial_btpe(rng, s);
+      if (X > s.bound) {  // (ten standard deviations out: the host sized its bounds for less; say so rather than overrun them)
+        atomicOr(&counters[C_FLAGS], F_CAPACITY);
+        X = s.bound;
+      }
+    } else {  // legacy random_binomial_inversion
+      double px = s.qn, U = rng.next_double();
+      while (U > px) {
+        ++X;
+        if (X > s.bound) {
+          X = 0;
+          px = s.qn;
+          U = rng.next_double();
+        } else {
+          U -= px;
+          px = ((double)(s.flow - X + 1) * s.p * px) / ((double)X * s.q);
+        }
       }
     }
     long long count = X;  // np.round of an integer

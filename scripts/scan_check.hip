@@ -25,7 +25,7 @@ int main() {
       CK(hipMemcpy(in, cnt.data(), (n + 1) * 4, hipMemcpyHostToDevice));
       for (unsigned stamp = 1; stamp <= 3; ++stamp) {
         CK(hipMemset(counters, 0, C_ALLOC * 4));
-        hipLaunchKernelGGL(k_scan_cells, dim3(nb), dim3(kBlock), 0, 0, in, out, n, desc, stamp, counters, tasks);
+        hipLaunchKernelGGL(k_scan_cells, dim3(nb), dim3(kBlock), 0, 0, in, out, n, desc, stamp, counters, tasks, kScanMaxPolls);
         CK(hipDeviceSynchronize());
       }
       std::vector<int> got(n + 1), ctr(C_ALLOC); std::vector<int2> tk(kMaxSortTasks);

@@ -489,31 +489,56 @@ def test_checkpoint_is_refused_while_a_promised_tick_is_pending(sc):
     assert len(eng.checkpoint_finish()["ids"]) == n
 
 
-def test_resume_after_the_fallback_to_the_host_stream(sc, tmp_path):
-    """A crate that started with the stream on the device and fell back to noise="host-sync" (a source outside the
-    inversion branch of the binomial) checkpoints the HOST stream -- the device's copy is stale by then -- and the
-    resumed run continues the uninterrupted one bit for bit."""
-    import warnings
+def big_flow_world(sc):
+    wc = scene(sc, "wave_machine")
+    wc.particle_sources = [dict(radius=0.3, position=[0.05, 0.95], velocity=[3, 0.0], flow=20000, noise=0.0, active_ticks=500)]
+    return wc  # flow * dt = 40 > 30: NumPy's legacy binomial takes its BTPE branch (particle_source.py:18)
 
-    def world():
-        wc = scene(sc, "wave_machine")
-        wc.particle_sources = [dict(radius=0.3, position=[0.05, 0.95], velocity=[3, 0.0], flow=20000, noise=0.0, active_ticks=500)]
-        return wc  # flow * dt = 40 > 30: BTPE
+
+def test_device_stream_with_the_btpe_binomial(sc):
+    """A source with flow * dt > 30 draws its count by BTPE; the device has that branch too (sc_rng.h), so noise="host"
+    stays on the device -- no warning, no fallback -- and gives what the host-drawn stream gives, bit for bit."""
+    import warnings
+    dev = sc.Crate(big_flow_world(sc), noise="host")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        for _ in range(40):
+            dev.physics_tick()
+    assert dev._noise == "host"
+    got = dev.engine.download()
+    dev.sync_host_rng()
+    after_dev = np.random.rand(4)
+    ref = sc.Crate(big_flow_world(sc), noise="host-sync")
+    for _ in range(40):
+        ref.physics_tick()
+    want = ref.engine.download()
+    assert len(want[3]) > 1200  # ~40 particles per tick
+    for x, y in zip(got, want):
+        assert np.array_equal(x, y)
+    assert np.array_equal(after_dev, np.random.rand(4))
+
+
+def test_resume_after_the_fallback_to_the_host_stream(sc, tmp_path):
+    """A crate that started with the stream on the device and fell back to noise="host-sync" (what a source with a time
+    step above one half makes it do; here the fallback is taken by hand after the first tick) checkpoints the HOST
+    stream -- the device's copy is stale by then -- and the resumed run continues the uninterrupted one bit for bit."""
+    def start():
+        crate = sc.Crate(big_flow_world(sc), noise="host")
+        crate.physics_tick()
+        with pytest.warns(RuntimeWarning, match="host-sync"):
+            crate._fall_back_to_host_stream()
+        assert crate._noise == "host-sync"
+        return crate
 
     def run(crate, ticks):
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore", RuntimeWarning)
-            for _ in range(ticks):
-                crate.physics_tick()
+        for _ in range(ticks):
+            crate.physics_tick()
 
-    a = sc.Crate(world(), noise="host")
-    with pytest.warns(RuntimeWarning, match="host-sync"):
-        a.physics_tick()
+    a = start()
     run(a, 23)
     want = a.engine.download()
-    b = sc.Crate(world(), noise="host")
-    run(b, 12)
-    assert b._noise == "host-sync"
+    b = start()
+    run(b, 11)
     b.save_checkpoint(tmp_path / "ck.npz")
     np.random.seed(7)
     c = sc.Crate.from_checkpoint(tmp_path / "ck.npz")

@@ -42,3 +42,20 @@ def test_source_emission_interleaved_with_noise_blocks():
             assert np.array_equal(rp, gp) and np.array_equal(rv, gv)
         k = 50 + 7 * tick                              # a collider-noise block of the tick (crate.py:169)
         assert np.array_equal(np.random.rand(k, 2), mine.rand(k, 2))
+
+
+def test_binomial_btpe_branch_matches_numpy():
+    """particle_source.py:18 with flow * dt > 30: NumPy's legacy generator switches to BTPE (rejection from a triangle,
+    two parallelograms and two exponential tails, with a squeeze); the restatement follows it draw for draw."""
+    for n, p in ((20000, 0.002), (7000, 0.01), (100000, 0.004), (500, 0.3), (70, 0.5), (50000, 0.49)):
+        assert n * p > 30.0
+        np.random.seed(4321)
+        mine = MT19937.from_numpy()
+        ref = [int(np.random.binomial(n, p)) for _ in range(1500)]
+        got = [binomial(mine, n, p) for _ in range(1500)]
+        assert got == ref
+        mine.to_numpy()  # ... and the stream stands where NumPy's stands
+        a = np.random.rand(3)
+        np.random.seed(4321)
+        [np.random.binomial(n, p) for _ in range(1500)]
+        assert np.array_equal(a, np.random.rand(3))
