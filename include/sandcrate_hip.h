@@ -145,8 +145,9 @@ int sc_step_finish(sc_ctx* ctx);
 int sc_step(sc_ctx* ctx, int32_t n_ticks);
 /* One whole tick in ONE call, for drivers whose per-call overhead matters (ctypes: ~4 us per call):
  *   sc_set_params(now) + sc_set_segments(now) + sc_step_begin + [sc_set_next_inputs(next)] + sc_step_finish.
- * `next` may be NULL (no look-ahead).  Same errors as the calls it stands for; not valid in
- * SC_NOISE_HOST mode (the host has to draw the noise between begin and finish, crate.py:169). */
+ * `next` may be NULL (no look-ahead).  Same errors as the calls it stands for; in SC_NOISE_HOST mode
+ * valid only when the device holds the stream (sc_rng_set_state) -- otherwise the host has to draw the noise
+ * between begin and finish (crate.py:169). */
 typedef struct sc_tick_inputs {
   sc_params params;
   const double* segments; /* n_segments x 2 x 2 (crate.py:69-71) */
@@ -184,6 +185,10 @@ int sc_neighbor_search(int device, const double* xy, int64_t n, double diameter,
                        int64_t* sorted_indices, int32_t* counts, int64_t* table);
 int sc_points_to_segments(int device, const double* xy, int64_t n, const double* segments, int32_t n_segments,
                           double* nearest, double* distances);
+/* pad_segments (geometry_utils.py:146-172) on the host, the reference's operations in its order: `padded` receives
+ * 2 * n_segments segments, first every (a + o, b + o), then every (b - o, a - o), o = cw90(b - a) * pad_distance / |b - a|.
+ * No GPU involved: the padded twins of a moving wall are a kernel argument of every tick (sc_set_segments). */
+int sc_pad_segments(const double* segments, int32_t n_segments, double pad_distance, double* padded);
 
 /* Kernel timing with HIP events on the context's stream.  While enabled every kernel launch is
  * bracketed by two events; sc_get_timing synchronises and returns, per kernel, the summed

@@ -90,6 +90,7 @@ SIGNATURES = {
     "sc_download_normals": (C.c_int, [_P, _D, C.c_int64, _I64]),
     "sc_neighbor_search": (C.c_int, [C.c_int, _D, C.c_int64, C.c_double, _I64, _I64, _I32, _I64]),
     "sc_points_to_segments": (C.c_int, [C.c_int, _D, C.c_int64, _D, C.c_int32, _D, _D]),
+    "sc_pad_segments": (C.c_int, [_D, C.c_int32, C.c_double, _D]),
     "sc_enable_timing": (C.c_int, [_P, C.c_int]),
     "sc_reset_timing": (C.c_int, [_P]),
     "sc_get_timing": (C.c_int, [_P, _D, _I64]),
@@ -149,7 +150,9 @@ def check(rc: int) -> None:
 
 
 def dptr(a: np.ndarray | None):
-    return None if a is None else a.ctypes.data_as(_D)
+    # (ctypes.cast of the raw address: a quarter of `a.ctypes.data_as`'s time, and this runs several times per tick;
+    # the caller keeps `a` alive)
+    return None if a is None else C.cast(a.__array_interface__["data"][0], _D)
 
 
 def i64ptr(a: np.ndarray | None):

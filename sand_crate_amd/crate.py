@@ -66,13 +66,16 @@ def tick_geometry(rigid_bodies, particle_radius, cache):
     plus, minus = [], []
     for body in rigid_bodies:
         hit = cache.get(id(body))
-        if hit is None or hit[0] != particle_radius or not np.array_equal(hit[1], body.segments):
+        # (a body that moves gets a new `segments` array every tick -- rigid_body.py: apply_velocity -- so the identity of
+        # the array says whether the cached halves still belong to it; the contents are compared only for the same array,
+        # which somebody may have edited in place)
+        if hit is None or hit[0] != particle_radius or hit[1] is not body.segments or hit[2].tobytes() != body.segments.tobytes():
             pad = pad_segments(body.segments, particle_radius)
-            hit = (particle_radius, body.segments.copy(), pad[: len(body)], pad[len(body):])
+            hit = (particle_radius, body.segments, body.segments.copy(), pad[: len(body)], pad[len(body):])
             cache[id(body)] = hit
-        plus.append(hit[2])
-        minus.append(hit[3])
-    seg = np.vstack([body.segments for body in rigid_bodies])
+        plus.append(hit[3])
+        minus.append(hit[4])
+    seg = np.concatenate([body.segments for body in rigid_bodies])
     bodies = [(b.position, b.center_velocity, b.angular_clockwise_velocity, len(b)) for b in rigid_bodies]
     return seg, np.concatenate(plus + minus), bodies
 
@@ -226,14 +229,13 @@ class Crate:
         self.debug_arrows = []
         for body in self.rigid_bodies:  # crate.py:363-365
             body.apply_velocity(self.dt)
-        self._send_tick_inputs()
         eng = self._engine
-        if self._noise == "host":    # the stream lives on the device: nothing comes back, nothing goes up
-            eng.step_begin()
-            eng.step_finish()
+        if self._noise == "host":    # the stream lives on the device: nothing comes back, nothing goes up --
+            eng.tick(self._pack_tick_inputs())  # ... and the whole tick is one library call
             self._count_known = False
             self.last_stats = None
         elif self._noise == "host-sync":
+            self._send_tick_inputs()
             eng.step_begin()
             stats = eng.step_stats()
             self.last_stats = stats
@@ -242,7 +244,7 @@ class Crate:
             eng.step_finish()
             self._count, self._count_known = stats.particles, True
         else:
-            eng.step(1)
+            eng.tick(self._pack_tick_inputs())
             self._count_known = False
         self._accelerate_free_bodies()
         self._cache = None

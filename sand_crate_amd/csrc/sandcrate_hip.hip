@@ -138,6 +138,7 @@ struct sc_ctx {
   int64_t idAlloc = 0;
   double* eta = nullptr;
   int64_t etaAlloc = 0, etaPairs = 0;
+  bool offsets_pending = false;  // the offsets of this tick are left to the launch that draws the noise (k_rng_noise_small)
   // staging for uploads
   double *stage_xy = nullptr, *stage_vxy = nullptr;
   int64_t stageAlloc = 0;
@@ -781,6 +782,15 @@ int sc_set_noise_mode(sc_ctx* c, int mode, uint64_t seed) {
   return SC_OK;
 }
 
+// host-noise mode: every particle's offset into the tick's rand(sum C_i, 2) block (crate.py:165-170 draws in id order)
+static int launch_noise_offsets(sc_ctx* c) {
+  Bracket br(c, K_NOISE_OFFSETS);
+  HIPCHK(hipMemsetAsync(c->cntById, 0, c->next_id * sizeof(int), c->stream));
+  hipLaunchKernelGGL(k_count_by_id, dim3(grid_for(launch_bound(c))), dim3(kBlock), 0, c->stream, c->counters, c->id[1],
+                     (const unsigned int*)c->rows, c->cntById);
+  return launch_scan(c, c->cntById, c->offById, c->next_id, c->idBlockSums, nullptr);
+}
+
 int sc_step_begin(sc_ctx* c) {
   if (!c) return fail(SC_ERR_ARG, "null context");
   if (c->in_step) return fail(SC_ERR_STATE, "sc_step_begin called twice");
@@ -858,14 +868,16 @@ int sc_step_begin(sc_ctx* c) {
     launch_pass_a<SC_NOISE_COUNTER, true, true>(c, K_PASS_A);
   else
     launch_pass_a<SC_NOISE_NONE, true, true>(c, K_PASS_A);
+  c->offsets_pending = false;
   if (c->noise_mode == SC_NOISE_HOST && c->next_id > 0) {
     rc = ensure_ids(c, c->next_id);
     if (rc) return rc;
-    Bracket br(c, K_NOISE_OFFSETS);
-    HIPCHK(hipMemsetAsync(c->cntById, 0, c->next_id * sizeof(int), c->stream));
-    hipLaunchKernelGGL(k_count_by_id, dim3(grid), dim3(kBlock), 0, c->stream, c->counters, c->id[1], (const unsigned int*)c->rows, c->cntById);
-    rc = launch_scan(c, c->cntById, c->offById, c->next_id, c->idBlockSums, nullptr);
-    if (rc) return rc;
+    // a small world whose stream the device holds: the offsets are taken by the same launch that draws the noise
+    // (sc_step_finish: k_rng_noise_small) -- unless the host brings its own block after all (sc_set_noise_host)
+    if (c->rng && c->next_id <= kSmallIds)
+      c->offsets_pending = true;
+    else if ((rc = launch_noise_offsets(c)))
+      return rc;
   }
   HIPCHK(hipGetLastError());
   c->in_step = true;
@@ -894,6 +906,11 @@ int sc_step_stats(sc_ctx* c, sc_stats* out) {
 int sc_set_noise_host(sc_ctx* c, const double* u01, int64_t n_pairs) {
   if (!c || n_pairs < 0 || (n_pairs > 0 && !u01)) return fail(SC_ERR_ARG, "bad noise array");
   if (!c->in_step) return fail(SC_ERR_STATE, "sc_set_noise_host needs sc_step_begin first");
+  if (c->offsets_pending) {  // (the host draws this tick's block itself: the offsets into it are needed after all)
+    c->offsets_pending = false;
+    int rc = launch_noise_offsets(c);
+    if (rc) return rc;
+  }
   if (n_pairs > c->etaAlloc) {
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->eta) (void)hipFree(c->eta);
@@ -925,8 +942,13 @@ int sc_step_finish(sc_ctx* c) {
     }
     if (c->next_id > 0) {
       Bracket br(c, K_NOISE_OFFSETS);
-      hipLaunchKernelGGL(k_rng_noise, dim3(1), dim3(kRngBlock), 0, c->stream, c->rng, c->offById + c->next_id, c->eta,
-                         (long long)c->etaAlloc, c->counters);
+      if (c->offsets_pending)
+        hipLaunchKernelGGL(k_rng_noise_small, dim3(1), dim3(kRngBlock), 0, c->stream, c->rng, c->id[1], (const unsigned int*)c->rows,
+                           (int)c->next_id, c->cntById, c->offById, c->eta, (long long)c->etaAlloc, c->counters);
+      else
+        hipLaunchKernelGGL(k_rng_noise, dim3(1), dim3(kRngBlock), 0, c->stream, c->rng, c->offById + c->next_id, c->eta,
+                           (long long)c->etaAlloc, c->counters);
+      c->offsets_pending = false;
     }
     c->etaPairs = 0;
   }
@@ -998,7 +1020,9 @@ int sc_step(sc_ctx* c, int32_t n_ticks) {
 
 int sc_tick(sc_ctx* c, const sc_tick_inputs* now, const sc_tick_inputs* next) {
   if (!c || !now) return fail(SC_ERR_ARG, "null argument");
-  if (c->noise_mode == SC_NOISE_HOST) return fail(SC_ERR_STATE, "sc_tick is not available in SC_NOISE_HOST mode");
+  // (SC_NOISE_HOST needs the host's noise block between the two halves of a tick -- unless the device holds the stream)
+  if (c->noise_mode == SC_NOISE_HOST && !c->rng)
+    return fail(SC_ERR_STATE, "sc_tick is not available in SC_NOISE_HOST mode unless the device holds the stream (sc_rng_set_state)");
   int rc = sc_set_params(c, &now->params);
   if (rc) return rc;
   rc = sc_set_segments(c, now->segments, now->padded, now->n_segments, now->bodies, now->n_bodies);
@@ -1250,6 +1274,26 @@ int sc_neighbor_search(int device, const double* xy, int64_t n, double diameter,
   sc_destroy(c);
   g_err = keep;
   return rc;
+}
+
+// geometry_utils.py:146-172 (pad_segments) on the host, operation for operation: o = cw90(b - a) * pad / |b - a| with the
+// norm as np.linalg.norm takes it for two components (sqrt of the sum of the squares, separately rounded -- this file is
+// compiled with -ffp-contract=off); first every (a + o, b + o), then every (b - o, a - o).  In the library because the
+// padded twins of a moving wall are needed every tick and the NumPy form of these thirty operations costs the host 15-25 us.
+int sc_pad_segments(const double* segments, int32_t ns, double pad_distance, double* padded) {
+  if (ns < 0 || (ns > 0 && (!segments || !padded))) return fail(SC_ERR_ARG, "bad arguments");
+  for (int k = 0; k < ns; ++k) {
+    const double ax = segments[4 * k], ay = segments[4 * k + 1], bx = segments[4 * k + 2], by = segments[4 * k + 3];
+    const double alx = bx - ax, aly = by - ay;
+    const double nx = aly, ny = -alx;  // clockwise quarter turn of (end - start)
+    const double norm = std::sqrt(nx * nx + ny * ny);
+    const double ox = nx * pad_distance / norm, oy = ny * pad_distance / norm;
+    double* plus = padded + 4 * k;
+    double* minus = padded + 4 * (ns + k);
+    plus[0] = ax + ox; plus[1] = ay + oy; plus[2] = bx + ox; plus[3] = by + oy;
+    minus[0] = bx - ox; minus[1] = by - oy; minus[2] = ax - ox; minus[3] = ay - oy;
+  }
+  return SC_OK;
 }
 
 int sc_points_to_segments(int device, const double* xy, int64_t n, const double* segments, int32_t ns, double* nearest,

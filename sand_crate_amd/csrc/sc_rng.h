@@ -203,14 +203,12 @@ __global__ void k_rng_emit(SourcesK srcs, long long max_particles, RngState* __r
 // and turned into doubles by all threads; a double whose two words straddle a block boundary is finished by
 // thread 0 with the carried word.
 constexpr int kRngBlock = 1024;
-__global__ void __launch_bounds__(kRngBlock)
-    k_rng_noise(RngState* __restrict__ state, const int* __restrict__ pairs_ptr, double* __restrict__ eta,
-                long long eta_pairs_room, int* __restrict__ counters) {
-  __shared__ uint32_t mt[kMtN];
+// (the workgroup's part: `mt` is 624 words of LDS, `pairs` the same in every thread)
+__device__ __forceinline__ void rng_noise_block(uint32_t* mt, RngState* __restrict__ state, long long pairs, double* __restrict__ eta,
+                                                long long eta_pairs_room, int* __restrict__ counters) {
   const int tid = threadIdx.x;
   for (int k = tid; k < kMtN; k += kRngBlock) mt[k] = state->mt[k];
   int pos = state->pos;
-  long long pairs = *pairs_ptr;
   if (pairs > eta_pairs_room) {
     if (tid == 0) atomicOr(&counters[C_FLAGS], F_CAPACITY);
     pairs = eta_pairs_room;
@@ -261,6 +259,51 @@ __global__ void __launch_bounds__(kRngBlock)
   }
   for (int k = tid; k < kMtN; k += kRngBlock) state->mt[k] = mt[k];
   if (tid == 0) state->pos = pos;
+}
+
+__global__ void __launch_bounds__(kRngBlock)
+    k_rng_noise(RngState* __restrict__ state, const int* __restrict__ pairs_ptr, double* __restrict__ eta,
+                long long eta_pairs_room, int* __restrict__ counters) {
+  __shared__ uint32_t mt[kMtN];
+  rng_noise_block(mt, state, *pairs_ptr, eta, eta_pairs_room, counters);
+}
+
+// A small world's noise in ONE launch (the viewer's scenes hold a few thousand particles: their tick is a dozen launches of
+// a few microseconds each, and five of them were these): the neighbor counts by particle id (zero, scatter), their
+// exclusive scan -- the offsets into the tick's rand(sum C_i, 2) block, crate.py:165-170 draws particle by particle in id
+// order -- and the block itself, by one workgroup.  `ids`: the host's bound of the ids handed out (at most kSmallIds).
+constexpr int kSmallIds = 1 << 16;
+__global__ void __launch_bounds__(kRngBlock)
+    k_rng_noise_small(RngState* __restrict__ state, const int* __restrict__ id, const unsigned int* __restrict__ rows, int ids,
+                      int* __restrict__ cntById, int* __restrict__ offById, double* __restrict__ eta, long long eta_pairs_room,
+                      int* __restrict__ counters) {
+  __shared__ uint32_t mt[kMtN];
+  __shared__ int waveTot[kRngBlock / 64];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n = counters[C_NT];
+  for (int k = tid; k < ids; k += kRngBlock) cntById[k] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += kRngBlock) cntById[id[i]] = (int)rows[(size_t)i * kRowWords + kRowCount];
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < ids; base += kRngBlock) {  // (uniform trip count)
+    const int k = base + tid;
+    const int v = k < ids ? cntById[k] : 0;
+    const int incl = wave_scan_add(v);
+    if (lane == 63) waveTot[wv] = incl;
+    __syncthreads();
+    int before = carry_s;
+    for (int w = 0; w < wv; ++w) before += waveTot[w];
+    if (k < ids) offById[k] = before + incl - v;
+    __syncthreads();
+    if (tid == kRngBlock - 1) carry_s = before + incl;
+    __syncthreads();
+  }
+  const long long pairs = carry_s;
+  if (tid == 0) offById[ids] = (int)pairs;
+  __syncthreads();
+  rng_noise_block(mt, state, pairs, eta, eta_pairs_room, counters);
 }
 
 }  // namespace sc

@@ -7,6 +7,7 @@ between ticks; nothing is copied back unless asked for.
 from __future__ import annotations
 
 import ctypes as C
+import struct
 from dataclasses import dataclass
 
 import numpy as np
@@ -27,6 +28,12 @@ _COEF_ORDER = ("dt", "particle_radius", "wall_collision_decay", "pressure_amplif
                "collider_noise_level", "viscosity", "surface_smoothing", "target_pressure")
 
 
+_BODY_FMT, _BODY_SIZE = "<5dii", C.sizeof(N.Body)
+_PARAMS_FMT = f"<{len(_COEF_ORDER) + 2}d"
+assert struct.calcsize(_BODY_FMT) == _BODY_SIZE and struct.calcsize(_PARAMS_FMT) == C.sizeof(N.Params)
+assert N.TickInputs.params.offset == 0
+
+
 class PackedInputs:
     """sc_tick_inputs plus the NumPy buffers it points into (kept alive with it)."""
 
@@ -39,10 +46,12 @@ class PackedInputs:
             raise ValueError("padded must hold two segments per wall segment")
         bodies = list(bodies)
         arr = (N.Body * max(len(bodies), 1))()
+        # (packed straight into the C structs: this runs every tick, and a ctypes constructor per body and field costs
+        # the host more than the GPU spends on a small scene's kernel)
         for k, (pos, vel, omega, nseg) in enumerate(bodies):
-            arr[k] = N.Body(float(pos[0]), float(pos[1]), float(vel[0]), float(vel[1]), float(omega), int(nseg), 0)
+            struct.pack_into(_BODY_FMT, arr, _BODY_SIZE * k, pos[0], pos[1], vel[0], vel[1], omega, nseg, 0)
         t = N.TickInputs()
-        t.params = N.Params(*(float(coef[k]) for k in _COEF_ORDER), float(gravity[0]), float(gravity[1]))
+        struct.pack_into(_PARAMS_FMT, t, 0, *[coef[k] for k in _COEF_ORDER], gravity[0], gravity[1])
         t.segments = N.dptr(seg)
         t.padded = N.dptr(pad)
         t.bodies = arr

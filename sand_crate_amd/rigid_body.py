@@ -14,6 +14,9 @@ import math
 import numpy as np
 
 
+_CW90 = np.array([1.0, -1.0])
+
+
 def _rotate_ccw_degrees(points: np.ndarray, angle: float) -> np.ndarray:
     """Rotation as pygame.Vector2.rotate performs it (rigid_body.py:38-39): fold the angle into
     [0, 360), treat right angles exactly, otherwise sin/cos of the folded angle in radians."""
@@ -62,11 +65,14 @@ class RigidBody:
     def apply_velocity(self, dt: float) -> None:
         # rigid_body.py:42-46: every end point += (center_velocity + cw90(point - position) * omega) * dt,
         # both ends of all segments in one pass (the same float64 operations per element)
+        # (few NumPy calls: this runs once per body and tick on the host, next to a GPU tick of tens of microseconds)
         seg = self.segments
         rel = seg - np.asarray(self.position, dtype=np.float64)
-        tangent = np.stack((rel[..., 1], -rel[..., 0]), axis=-1)  # clockwise quarter turn
-        velocity = np.asarray(self.center_velocity, dtype=np.float64) + tangent * self.angular_clockwise_velocity
-        self.segments = seg + velocity * dt
+        tangent = rel[..., ::-1] * _CW90  # clockwise quarter turn (y, -x): the products by 1 and -1 are exact
+        tangent *= self.angular_clockwise_velocity
+        tangent += np.asarray(self.center_velocity, dtype=np.float64)  # = center_velocity + tangent * omega
+        tangent *= dt
+        self.segments = seg + tangent
 
 
 class FixedRigidBody(RigidBody):

@@ -18,7 +18,16 @@ def rotate_vectors_clockwise_90_deg(vectors: np.ndarray) -> np.ndarray:
 
 def pad_segments(segments: np.ndarray, pad_distance: float) -> np.ndarray:
     """Two parallel copies of every segment at +-pad_distance: first all (a+o, b+o), then all
-    (b-o, a-o), with o = cw90(b - a) * pad_distance / |b - a|."""
+    (b-o, a-o), with o = cw90(b - a) * pad_distance / |b - a| -- computed by the library on the host
+    (sc_pad_segments: the reference's operations in its order; `pad_segments_numpy` below is the same in NumPy,
+    kept as the check of it)."""
+    seg = N.f64(segments).reshape(-1, 2, 2)
+    out = np.empty((2 * len(seg), 2, 2))
+    N.check(N.load().sc_pad_segments(N.dptr(seg), len(seg), float(pad_distance), N.dptr(out)))
+    return out
+
+
+def pad_segments_numpy(segments: np.ndarray, pad_distance: float) -> np.ndarray:
     segments = np.asarray(segments, dtype=np.float64)
     n = len(segments)
     start, end = segments[:, 0, :], segments[:, 1, :]

