@@ -595,7 +595,8 @@ def test_a_scan_that_gives_up_skips_the_tick(sc):
     assert np.array_equal(before[1], after[1]) and np.array_equal(before[3], after[3])
     moved = np.flatnonzero((before[0] != after[0]).any(axis=1))
     r = crate.particle_radius
-    assert len(moved) < 0.01 * len(p) and np.abs(before[0][moved] - after[0][moved]).max(initial=0.0) <= 0.21 * r
+    # (the motored wall kept moving through the abandoned ticks -- the host runs the bodies -- and pushed what it reached)
+    assert len(moved) < 0.01 * len(p) and np.abs(before[0][moved] - after[0][moved]).max(initial=0.0) <= 1.2 * r
     crate.engine.set_scan_patience(1 << 22)
     crate.run(2)                                        # ... and the run goes on from there
     crate.synchronize()
