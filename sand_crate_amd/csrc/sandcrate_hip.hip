@@ -943,7 +943,7 @@ int sc_step_finish(sc_ctx* c) {
     if (c->next_id > 0) {
       Bracket br(c, K_NOISE_OFFSETS);
       if (c->offsets_pending)
-        hipLaunchKernelGGL(k_rng_noise_small, dim3(1), dim3(kRngBlock), 0, c->stream, c->rng, c->id[1], (const unsigned int*)c->rows,
+        hipLaunchKernelGGL(k_rng_noise_small, dim3(1), dim3(kSmallBlock), 0, c->stream, c->rng, c->id[1], (const unsigned int*)c->rows,
                            (int)c->next_id, c->cntById, c->offById, c->eta, (long long)c->etaAlloc, c->counters);
       else
         hipLaunchKernelGGL(k_rng_noise, dim3(1), dim3(kRngBlock), 0, c->stream, c->rng, c->offById + c->next_id, c->eta,

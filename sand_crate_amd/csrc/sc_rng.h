@@ -198,16 +198,35 @@ __global__ void k_rng_emit(SourcesK srcs, long long max_particles, RngState* __r
   state->pos = rng.pos;
 }
 
-// The collider noise of one tick: 2 * pairs doubles from the stream into eta, in order.  One workgroup: a state
-// block of 624 words is regenerated in three dependent phases (the recurrence reaches 227 words back), tempered
-// and turned into doubles by all threads; a double whose two words straddle a block boundary is finished by
-// thread 0 with the carried word.
-constexpr int kRngBlock = 1024;
-// (the workgroup's part: `mt` is 624 words of LDS, `pairs` the same in every thread)
-__device__ __forceinline__ void rng_noise_block(uint32_t* mt, RngState* __restrict__ state, long long pairs, double* __restrict__ eta,
-                                                long long eta_pairs_room, int* __restrict__ counters) {
+// The collider noise of one tick: 2 * pairs doubles from the stream into eta, in order.  FOUR WAVES: the recurrence
+// x[n + 624] = f(x[n], x[n + 1], x[n + 397]) reaches 227 words back, so a state block of 624 words is regenerated in three
+// dependent phases of at most 227 independent words -- a word per thread, a workgroup barrier between the reads and the
+// writes of a phase (thread k reads what thread k + 1 overwrites) and one behind the writes --; the block is then
+// tempered and turned into doubles by all 256 threads; a double whose two words straddle a block boundary is finished
+// with the carried word.  (Measured on the viewer's scene, 77 blocks per tick: 1,024 threads -- sixteen waves at every
+// barrier -- 100 us; ONE wave without any barrier 150 us: a lone wave issues an instruction every 5-9 clocks and the
+// tempering is ~35 instructions per double; four waves: see DESIGN.md.)
+constexpr int kRngBlock = 256;
+// (the first kRngBlock threads of a workgroup call this -- all of them --; `mt`: 624 words of LDS; `bar`: a barrier
+// those threads, and only they, meet: the workgroup's own for a workgroup of kRngBlock threads)
+// A workgroup barrier that orders LDS accesses only: __syncthreads() also waits for the thread's outstanding GLOBAL stores
+// (s_waitcnt vmcnt(0)), and the loop below stores a block's doubles to global memory in every round -- each barrier then
+// cost a store's round trip to memory.
+struct LdsBarrier {
+  __device__ __forceinline__ void operator()() const { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+};
+
+template <class Barrier>
+__device__ __forceinline__ void rng_noise_block(uint32_t* mt2, RngState* __restrict__ state, long long pairs, double* __restrict__ eta,
+                                                long long eta_pairs_room, int* __restrict__ counters, Barrier bar) {
+  // `mt2`: TWO state blocks of LDS.  A regeneration reads the current block and writes the other one, so a phase needs
+  // no barrier between its reads and its writes -- three barriers per block, one behind each phase's writes (nine with
+  // one block in place; the kernel is a chain of barriers and LDS round trips, ~0.1 us each at the clocks a one-workgroup
+  // kernel runs at).
+  uint32_t* cur = mt2;
+  uint32_t* nxt = mt2 + kMtN;
   const int tid = threadIdx.x;
-  for (int k = tid; k < kMtN; k += kRngBlock) mt[k] = state->mt[k];
+  for (int k = tid; k < kMtN; k += kRngBlock) cur[k] = state->mt[k];
   int pos = state->pos;
   if (pairs > eta_pairs_room) {
     if (tid == 0) atomicOr(&counters[C_FLAGS], F_CAPACITY);
@@ -217,28 +236,32 @@ __device__ __forceinline__ void rng_noise_block(uint32_t* mt, RngState* __restri
   long long w = 0;
   bool have_carry = false;
   uint32_t carry = 0;
-  __syncthreads();
-  while (w < need) {  // every variable that steers this loop is uniform over the workgroup
+  constexpr int kSpan = kMtN - kMtM;  // 227: the words of a phase
+  static_assert(kSpan <= kRngBlock, "a phase is one word per thread");
+  bar();
+  while (w < need) {  // every variable that steers this loop is uniform over the threads
     if (pos >= kMtN) {
-      // kk in [0, 227): old words only; [227, 454): new words of the first phase; [454, 624): of the second
-      // (word 623 also takes the NEW word 0)
+      // word kk of the new block from words kk, kk + 1 of the current one and word kk + 397 -- of the current block up to
+      // kk = 226, of the NEW block (kk - 227) beyond: hence the phases [0, 227), [227, 454), [454, 624); the last word
+      // takes the new word 0 as its successor
+#pragma unroll
       for (int phase = 0; phase < 3; ++phase) {
-        const int kk = phase * (kMtN - kMtM) + tid;
-        const int end = phase == 2 ? kMtN : (phase + 1) * (kMtN - kMtM);
-        uint32_t v = 0;
-        const bool mine = tid < kMtN - kMtM && kk < end;
-        if (mine) v = mt_twist(mt[kk], mt[(kk + 1) % kMtN], mt[(kk + kMtM) % kMtN]);
-        __syncthreads();
-        if (mine && kk != kMtN - 1) mt[kk] = v;
-        __syncthreads();
-        if (phase == 2 && tid == 0) mt[kMtN - 1] = mt_twist(mt[kMtN - 1], mt[0], mt[kMtM - 1]);
-        __syncthreads();
+        const int kk = phase * kSpan + tid;
+        if (tid < kSpan && kk < kMtN) {
+          const uint32_t succ = kk + 1 < kMtN ? cur[kk + 1] : nxt[0];
+          const uint32_t far = kk + kMtM < kMtN ? cur[kk + kMtM] : nxt[kk + kMtM - kMtN];
+          nxt[kk] = mt_twist(cur[kk], succ, far);
+        }
+        bar();
       }
+      uint32_t* t = cur;
+      cur = nxt;
+      nxt = t;
       pos = 0;
     }
     int start = pos;
     if (have_carry) {
-      if (tid == 0) eta[w] = mt_double(carry, mt_temper(mt[start]));
+      if (tid == 0) eta[w] = mt_double(carry, mt_temper(cur[start]));
       w += 1;
       start += 1;
       have_carry = false;
@@ -246,26 +269,26 @@ __device__ __forceinline__ void rng_noise_block(uint32_t* mt, RngState* __restri
     const long long left = need - w;
     const int nd = (int)min((long long)((kMtN - start) / 2), left);
     for (int k = tid; k < nd; k += kRngBlock)
-      eta[w + k] = mt_double(mt_temper(mt[start + 2 * k]), mt_temper(mt[start + 2 * k + 1]));
+      eta[w + k] = mt_double(mt_temper(cur[start + 2 * k]), mt_temper(cur[start + 2 * k + 1]));
     w += nd;
     start += 2 * nd;
     if (w < need && start == kMtN - 1) {
-      carry = mt_temper(mt[kMtN - 1]);
+      carry = mt_temper(cur[kMtN - 1]);
       have_carry = true;
       start = kMtN;
     }
     pos = start;
-    __syncthreads();
   }
-  for (int k = tid; k < kMtN; k += kRngBlock) state->mt[k] = mt[k];
+  bar();
+  for (int k = tid; k < kMtN; k += kRngBlock) state->mt[k] = cur[k];
   if (tid == 0) state->pos = pos;
 }
 
 __global__ void __launch_bounds__(kRngBlock)
     k_rng_noise(RngState* __restrict__ state, const int* __restrict__ pairs_ptr, double* __restrict__ eta,
                 long long eta_pairs_room, int* __restrict__ counters) {
-  __shared__ uint32_t mt[kMtN];
-  rng_noise_block(mt, state, *pairs_ptr, eta, eta_pairs_room, counters);
+  __shared__ uint32_t mt[2 * kMtN];
+  rng_noise_block(mt, state, *pairs_ptr, eta, eta_pairs_room, counters, LdsBarrier{});
 }
 
 // A small world's noise in ONE launch (the viewer's scenes hold a few thousand particles: their tick is a dozen launches of
@@ -273,37 +296,47 @@ __global__ void __launch_bounds__(kRngBlock)
 // exclusive scan -- the offsets into the tick's rand(sum C_i, 2) block, crate.py:165-170 draws particle by particle in id
 // order -- and the block itself, by one workgroup.  `ids`: the host's bound of the ids handed out (at most kSmallIds).
 constexpr int kSmallIds = 1 << 16;
-__global__ void __launch_bounds__(kRngBlock)
+constexpr int kSmallBlock = kRngBlock;  // (the scan of the ids and the stream share the workgroup)
+__global__ void __launch_bounds__(kSmallBlock)
     k_rng_noise_small(RngState* __restrict__ state, const int* __restrict__ id, const unsigned int* __restrict__ rows, int ids,
                       int* __restrict__ cntById, int* __restrict__ offById, double* __restrict__ eta, long long eta_pairs_room,
                       int* __restrict__ counters) {
-  __shared__ uint32_t mt[kMtN];
-  __shared__ int waveTot[kRngBlock / 64];
+  __shared__ uint32_t mt[2 * kMtN];
+  __shared__ int waveTot[kSmallBlock / 64];
   __shared__ int carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = counters[C_NT];
-  for (int k = tid; k < ids; k += kRngBlock) cntById[k] = 0;
+  for (int k = tid; k < ids; k += kSmallBlock) cntById[k] = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += kRngBlock) cntById[id[i]] = (int)rows[(size_t)i * kRowWords + kRowCount];
+  for (int i = tid; i < n; i += kSmallBlock) cntById[id[i]] = (int)rows[(size_t)i * kRowWords + kRowCount];
   if (tid == 0) carry_s = 0;
   __syncthreads();
-  for (int base = 0; base < ids; base += kRngBlock) {  // (uniform trip count)
-    const int k = base + tid;
-    const int v = k < ids ? cntById[k] : 0;
-    const int incl = wave_scan_add(v);
+  // exclusive scan over the ids, every thread a run of consecutive ids: its loads are all in flight together (one
+  // round trip -- an id per thread and step was a chain of dependent global loads, ~2 us each), one scan of the
+  // threads' totals across the workgroup, then the run is walked again for the offsets
+  {
+    const int per = (ids + kSmallBlock - 1) / kSmallBlock, k0 = tid * per, k1 = min(k0 + per, ids);
+    int sum = 0;
+    for (int k = k0; k < k1; ++k) sum += cntById[k];
+    const int incl = wave_scan_add(sum);
     if (lane == 63) waveTot[wv] = incl;
     __syncthreads();
-    int before = carry_s;
-    for (int w = 0; w < wv; ++w) before += waveTot[w];
-    if (k < ids) offById[k] = before + incl - v;
-    __syncthreads();
-    if (tid == kRngBlock - 1) carry_s = before + incl;
+    int before = 0, total = 0;
+    for (int w = 0; w < kSmallBlock / 64; ++w) {
+      if (w < wv) before += waveTot[w];
+      total += waveTot[w];
+    }
+    int run = before + incl - sum;
+    for (int k = k0; k < k1; ++k) {
+      offById[k] = run;
+      run += cntById[k];
+    }
+    if (tid == 0) carry_s = total;
     __syncthreads();
   }
   const long long pairs = carry_s;
   if (tid == 0) offById[ids] = (int)pairs;
-  __syncthreads();
-  rng_noise_block(mt, state, pairs, eta, eta_pairs_room, counters);
+  rng_noise_block(mt, state, pairs, eta, eta_pairs_room, counters, LdsBarrier{});
 }
 
 }  // namespace sc

@@ -512,7 +512,7 @@ def test_device_stream_with_the_btpe_binomial(sc):
     for _ in range(40):
         ref.physics_tick()
     want = ref.engine.download()
-    assert len(want[3]) > 1200  # ~40 particles per tick
+    assert len(want[3]) > 500 and want[3].max() > 1200  # ~40 particles per tick (many have left the box again)
     for x, y in zip(got, want):
         assert np.array_equal(x, y)
     assert np.array_equal(after_dev, np.random.rand(4))
