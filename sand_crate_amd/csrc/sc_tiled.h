@@ -38,6 +38,9 @@ namespace sc {
 #ifndef SC_COOP
 #define SC_COOP 2
 #endif
+#ifndef SC_LEAD_IN
+#define SC_LEAD_IN 1
+#endif
 #ifndef SC_CAP_A
 #define SC_CAP_A 1024
 #define SC_CAP_AW 1536
@@ -388,17 +391,42 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       scan(live, self + 1, e0 - (i + 1), 1, [&](double xj, double xq) { return xj > xq + w.d ? 0 : 2; });
       SC_STAMP(0, 3);
       probe.hits_after_first(C);
+      // The scans of the adjacent strips start at a CELL's first particle, up to a cell's worth of candidates short of the
+      // window (x_i - d lies anywhere in the cell before the particle's): an LDS tile's thread first finds, among the
+      // first seven candidates, the ones that lie before the window even by the conservative stop distance -- x is
+      // monotone along a scan, three probes -- and starts behind them.  (What is skipped can be neither inside the
+      // window nor within the distance: the lists are the same.  A wave's scan runs as long as its slowest lane, and the
+      // lanes with the longest lead-in were the slowest.)
+      auto lead_in = [&](int first, int count, int step) -> int {
+        int s = 0;
+        if constexpr (LDS && SC_LEAD_IN) {
+#pragma unroll
+          for (int h = 4; h >= 1; h >>= 1) {
+            const int probe = s + h - 1;
+            const double xj = txy[first + min(probe, max(count - 1, 0)) * step].x;
+            const bool before = probe < count && (step > 0 ? xj < xi - dstop : xj > xi + dstop);
+            s += before ? h : 0;
+          }
+        }
+        return s;
+      };
       // next strip: x_i - d <= x_j <= x_i + d                                (:112-119)
-      scan(live && C < kMaxNbr, tl.n0 + (b1 - tl.a1), e1 - b1, 1,
-           [&](double xj, double xq) { return xj > xq + w.d ? 0 : (xj >= xq - w.d ? 2 : 1); });
+      {
+        const int first = tl.n0 + (b1 - tl.a1), count = e1 - b1, s = lead_in(first, count, 1);
+        scan(live && C < kMaxNbr, first + s, count - s, 1,
+             [&](double xj, double xq) { return xj > xq + w.d ? 0 : (xj >= xq - w.d ? 2 : 1); });
+      }
       SC_STAMP(0, 4);
       probe.hits_after_second(C);
       // reverse edges (:85-88): i is a forward candidate of j, same strip
       scan(live && C < kMaxNbr, self - 1, i - b0, -1, [&](double xj, double xq) { return !(xq <= xj + w.d) ? 0 : 2; });
       SC_STAMP(0, 5);
       // reverse edges from the previous strip
-      scan(live && C < kMaxNbr, tl.n0 + tl.n1 + (em - 1 - tl.a2), em - bm, -1,
-           [&](double xj, double xq) { return !(xq <= xj + w.d) ? 0 : (xq >= xj - w.d ? 2 : 1); });
+      {
+        const int first = tl.n0 + tl.n1 + (em - 1 - tl.a2), count = em - bm, s = lead_in(first, count, -1);
+        scan(live && C < kMaxNbr, first - s, count - s, -1,
+             [&](double xj, double xq) { return !(xq <= xj + w.d) ? 0 : (xq >= xj - w.d ? 2 : 1); });
+      }
       if constexpr (LDS) C = (int)((lo - lo0) / kRow);
       probe.flush();
     } else if (live) {
