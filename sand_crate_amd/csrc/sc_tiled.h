@@ -51,7 +51,10 @@ constexpr int kTileW = SC_TILE_W;      // particles (= threads) per workgroup
 // whole grid is resident anyway (fewer tiles fall out of LDS); the launcher picks (measured: profiles/)
 constexpr int kTileCapA = SC_CAP_A, kTileCapAWide = SC_CAP_AW;
 constexpr int kTileCapB = SC_CAP_B;   // pass B tile: (x, y), (sx, sy), P of the three ranges: 40 B per entry, 37.5 KiB
-constexpr int kDenseTile = kTileW * 43 / 10;  // 1100 entries for 256 particles (the usual tile has ~800)
+#ifndef SC_DENSE_TILE
+#define SC_DENSE_TILE (SC_TILE_W * 43 / 10)
+#endif
+constexpr int kDenseTile = SC_DENSE_TILE;  // 1100 entries for 256 particles (the usual tile has ~800)
 constexpr int kSlotMax = 65535;  // lists are staged as u16 tile slots in pass A
 
 // The neighbor table: one 48-byte row per sorted particle -- twenty entries of 16 bits (tile slots, below) and the count --
