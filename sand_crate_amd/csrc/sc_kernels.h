@@ -192,6 +192,29 @@ constexpr int kMatchRounds = 12;
 // GROUP is a launch-time choice (the host launches the grouping variants while the scans report big buckets):
 // inlined into the fused epilogue of pass B the masks of the grouping loop cost that kernel eight more scalar
 // registers than it has -- +2.6 us per tick in the uniform regime for a path that regime never takes.
+// The same grouping over a whole WORKGROUP, in an LDS hash table of (cell, count): every particle finds or claims its
+// cell's slot (linear probing; at most blockDim.x <= kCellTabSlots / 2 distinct cells) and adds itself; one global atomic
+// per used slot follows.  Four times fewer atomics on a pile's counters than the waves' own groups send.
+#ifndef SC_WG_CELL_TABLE
+#define SC_WG_CELL_TABLE 3  // bit 0: the scatter, bit 1: the fused cell count of pass B
+#endif
+constexpr int kCellTabSlots = 512;
+__device__ __forceinline__ void cell_tab_clear(int* tkey, int* tcnt) {
+  for (int s = threadIdx.x; s < kCellTabSlots; s += blockDim.x) {
+    tkey[s] = -1;
+    tcnt[s] = 0;
+  }
+}
+__device__ __forceinline__ int cell_tab_insert(int* tkey, int cell) {  // cell >= 0; -> its slot
+  int s = (int)(((unsigned)cell * 2654435761u) >> 23);  // the product's top 9 bits
+  static_assert(kCellTabSlots == 1 << 9, "the hash keeps 9 bits");
+  for (;;) {
+    const int prev = atomicCAS(&tkey[s], -1, cell);
+    if (prev == -1 || prev == cell) return s;
+    s = (s + 1) & (kCellTabSlots - 1);
+  }
+}
+
 template <bool GROUP>
 __device__ __forceinline__ void count_cells(int c, int* __restrict__ cellCount) {
   const int lane = threadIdx.x & 63;
@@ -517,24 +540,23 @@ __global__ void __launch_bounds__(kSortBlock) SC_SORT_WAVES_ATTR
         pm[u] = kk.src;
       }
     }
+    // (and the thread's sample, below: every fourth key of the chunk)
+    constexpr int kSampleStride = kSortChunk / kSortBins;
+    const bool has_sample = tid < kSortBins && tid * kSampleStride < len;
+    SortKey smp{0.0, 0, 0};
+    if (has_sample) smp = keys[b + tid * kSampleStride];
     SC_STAMP(2, 1);
-    // 2. splitters: every thread contributes one of its keys as a sample; the 256 samples are sorted (bitonic network, keys
-    // (x, id) in their total order -- exact ties in x cannot unbalance the bins) and the first 255 of them split the
-    // chunk into 256 bins of ~8 keys
+    // 2. splitters: 256 samples of the chunk are sorted (bitonic network, keys (x, id) in their total order -- exact ties in
+    // x cannot unbalance the bins) and the first 255 of them split the chunk into 256 bins of ~4 keys
     __syncthreads();  // the previous task is done with the shared arrays
     {
-      // thread t < 256 contributes its (t mod kPerT)-th key as a sample when the chunk reaches that far: samples from all
-      // over the chunk (its arrival order follows the storage order, a sample of its head would know only one end of the
-      // x range)
-      double sx = tid < len ? x[0] : __builtin_huge_val();
-      int si = tid < len ? id[0] : 0x7FFFFFFF;
-#pragma unroll
-      for (int u = 1; u < kPerT; ++u) {
-        if ((tid & (kPerT - 1)) == u && tid + u * kSortBlock < len) {
-          sx = x[u];
-          si = id[u];
-        }
-      }
+      // thread t < 256 contributes key 4 t of the chunk as a sample (a chunk shorter than that has fewer samples, the rest
+      // sort behind every key): samples from all over the chunk, evenly spaced.  The chunk's order is the scatter's arrival
+      // order, i.e. stretches of the storage order -- of the previous tick's sorted order --, so neither a sample of its head
+      // nor one of two of its quarters (rounds 2-3: keys t and 512 + t) knows the whole x range once the scatter groups a
+      // workgroup's particles: k_sort_big 22 -> 37 us with bins of hundreds.
+      double sx = has_sample ? smp.x : __builtin_huge_val();
+      int si = has_sample ? smp.id : 0x7FFFFFFF;
       // the network: a stage whose partners sit in the same wave exchanges lane to lane -- on the DPP path when they are
       // less than 16 lanes apart (26 of the 36 stages), through the LDS crossbar for 16 and 32 (7) --, only the three
       // stages across waves go through LDS and a barrier (all 36 that way took 8 us of a 25 us task)
@@ -716,6 +738,38 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ coun
   // one address.  A wave that finds itself that scrambled (many run heads) groups its lanes by cell whatever their
   // order, one atomic per cell, for up to kMatchRounds cells; what is left goes one by one.
   int pos = -1;
+#if SC_WG_CELL_TABLE & 1
+  if constexpr (GROUP) {
+    // pile-up regime: the WORKGROUP's particles are grouped by cell in an LDS table (cell_tab_*), one returning atomic
+    // per cell and workgroup -- a quarter of what the waves' own groups sent to the hot counters
+    __shared__ int tkey[kCellTabSlots], tcnt[kCellTabSlots], tbase[kCellTabSlots];
+    cell_tab_clear(tkey, tcnt);
+    __syncthreads();
+    int slot = 0, rank = 0;
+    if (c >= 0) {
+      slot = cell_tab_insert(tkey, c);
+      rank = atomicAdd(&tcnt[slot], 1);
+    }
+    __syncthreads();
+    SC_STAMP(4, 2);
+    for (int s = threadIdx.x; s < kCellTabSlots; s += blockDim.x) {
+      const int k = tkey[s];
+      if (k >= 0) {
+        const int len = tcnt[s];
+        tbase[s] = bk(k) + atomicSub(&cellCount[k], len) - len;
+      }
+    }
+    __syncthreads();
+    pos = tbase[slot] + rank;
+    SC_STAMP(4, 3);
+    if (c >= 0) {
+      keys[pos] = SortKey{xi, idi, i};
+      keyCell[pos] = cpacked;
+    }
+    SC_STAMP(4, 4);
+    return;
+  }
+#endif
   LaneRun run = lane_run(c >= 0 ? c : -1 - lane);
   const bool scrambled = GROUP && __popcll(__ballot(run.is_head && c >= 0)) > kScrambledHeads;  // wave-uniform
   if (scrambled) {

@@ -1250,6 +1250,13 @@ __global__ void __launch_bounds__(kTileW)
       const int s = t + k * kTileW;
       if (s < total) txy[s] = rv[k];
     }
+#if SC_WG_CELL_TABLE & 2
+    if constexpr (GROUP && FUSED) {  // the pressures' array is free from here on: it takes the workgroup's cell table (below)
+      int* tkey = reinterpret_cast<int*>(tP);
+      cell_tab_clear(tkey, tkey + kCellTabSlots);
+      if (t == 0) tkey[2 * kCellTabSlots] = 0;  // waves that have added their particles
+    }
+#endif
     __syncthreads();
     SC_STAMP_B(4);
     if (active) {
@@ -1287,6 +1294,27 @@ __global__ void __launch_bounds__(kTileW)
       if (cnext >= 0) wslotS[i] = wsn;
     }
     SC_STAMP_B(18);
+#if SC_WG_CELL_TABLE & 2
+    if (GROUP && in_lds) {
+      // pile-up regime: the workgroup's particles are grouped by cell in LDS (cell_tab_*: sc_kernels.h), and the wave that
+      // adds its particles last sends one atomic per cell for all four -- no barrier: a wave's LDS operations execute in
+      // order, so whoever draws the last arrival number finds every other wave's entries in the table
+      static_assert(sizeof(double) * kTileCapB >= sizeof(int) * (2 * kCellTabSlots + 1), "the table lives in the pressures' array");
+      int* tkey = reinterpret_cast<int*>(tP);
+      int* tcnt = tkey + kCellTabSlots;
+      if (cnext >= 0) atomicAdd(&tcnt[cell_tab_insert(tkey, cnext & kCellMask)], 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (and the compiler keeps the arrival behind the entries)
+      int last = 0;
+      if ((t & 63) == 0) last = atomicAdd(&tkey[2 * kCellTabSlots], 1) == kTileW / 64 - 1;
+      asm volatile("" ::: "memory");
+      if (__builtin_amdgcn_readfirstlane(last)) {
+        for (int s = t & 63; s < kCellTabSlots; s += 64) {
+          const int k = tkey[s];
+          if (k >= 0) atomicAdd(&cellCount[k], tcnt[s]);
+        }
+      }
+    } else
+#endif
     count_cells<GROUP>(cnext, cellCount);  // every lane of the wave takes part
     SC_STAMP_B(19);
     // slabs: the coming tick's halo message is packed here too (same rule and same pre-wall-fix position as
