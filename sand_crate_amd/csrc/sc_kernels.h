@@ -195,9 +195,6 @@ constexpr int kMatchRounds = 12;
 // The same grouping over a whole WORKGROUP, in an LDS hash table of (cell, count): every particle finds or claims its
 // cell's slot (linear probing; at most blockDim.x <= kCellTabSlots / 2 distinct cells) and adds itself; one global atomic
 // per used slot follows.  Four times fewer atomics on a pile's counters than the waves' own groups send.
-#ifndef SC_WG_CELL_TABLE
-#define SC_WG_CELL_TABLE 3  // bit 0: the scatter, bit 1: the fused cell count of pass B
-#endif
 constexpr int kCellTabSlots = 512;
 __device__ __forceinline__ void cell_tab_clear(int* tkey, int* tcnt) {
   for (int s = threadIdx.x; s < kCellTabSlots; s += blockDim.x) {
@@ -733,15 +730,13 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ coun
   SC_STAMP(4, 1);
   const int lane = threadIdx.x & 63;
   // Storage order is the previous tick's sorted order, so the lanes of a run share a cell -- as long as particles
-  // stay near their cells.  In a pile-up they do not (the contract workload's particles cross more than a cell per
-  // tick by then): runs shrink to one or two lanes and a cell of thousands takes thousands of returning atomics on
-  // one address.  A wave that finds itself that scrambled (many run heads) groups its lanes by cell whatever their
-  // order, one atomic per cell, for up to kMatchRounds cells; what is left goes one by one.
+  // stay near their cells: one returning atomic per run.  In a pile-up they do not (the contract workload's particles cross
+  // more than a cell per tick by then): runs shrink to one or two lanes and a cell of thousands takes thousands of returning
+  // atomics on one address.  GROUP (launched while the scans report big buckets): the WORKGROUP's particles are grouped by
+  // cell in an LDS table (cell_tab_*), one returning atomic per cell and workgroup -- a quarter of what groups inside each
+  // wave (rounds 2-3) sent to the hot counters: 30.3 -> 18.2 us.
   int pos = -1;
-#if SC_WG_CELL_TABLE & 1
   if constexpr (GROUP) {
-    // pile-up regime: the WORKGROUP's particles are grouped by cell in an LDS table (cell_tab_*), one returning atomic
-    // per cell and workgroup -- a quarter of what the waves' own groups sent to the hot counters
     __shared__ int tkey[kCellTabSlots], tcnt[kCellTabSlots], tbase[kCellTabSlots];
     cell_tab_clear(tkey, tcnt);
     __syncthreads();
@@ -761,41 +756,8 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const int* __restrict__ coun
     }
     __syncthreads();
     pos = tbase[slot] + rank;
-    SC_STAMP(4, 3);
-    if (c >= 0) {
-      keys[pos] = SortKey{xi, idi, i};
-      keyCell[pos] = cpacked;
-    }
-    SC_STAMP(4, 4);
-    return;
-  }
-#endif
-  LaneRun run = lane_run(c >= 0 ? c : -1 - lane);
-  const bool scrambled = GROUP && __popcll(__ballot(run.is_head && c >= 0)) > kScrambledHeads;  // wave-uniform
-  if (scrambled) {
-    unsigned long long todo = __ballot(c >= 0);
-    int my_leader = -1, my_off = 0, my_len = 0;
-    for (int it = 0; it < kMatchRounds && todo; ++it) {
-      const int leader = __builtin_amdgcn_readfirstlane(__ffsll(todo) - 1);
-      const int kc = __builtin_amdgcn_readlane(c, leader);
-      const unsigned long long grp = __ballot(c == kc);
-      if (c == kc) {
-        my_leader = leader;
-        my_off = (int)__popcll(grp & ((1ull << lane) - 1ull));
-        my_len = (int)__popcll(grp);
-      }
-      todo &= ~grp;
-    }
-    if (c >= 0 && my_leader < 0) {  // cells beyond the rounds: one by one
-      my_leader = lane;
-      my_len = 1;
-    }
-    SC_STAMP(4, 2);
-    int base = 0;  // the groups' atomics leave together
-    if (my_leader == lane) base = bk(c) + atomicSub(&cellCount[c], my_len) - my_len;
-    base = __shfl(base, my_leader >= 0 ? my_leader : lane, 64);
-    pos = base + my_off;
   } else {
+    const LaneRun run = lane_run(c >= 0 ? c : -1 - lane);
     int base = 0;
     if (run.is_head && c >= 0) base = bk(c) + atomicSub(&cellCount[c], run.len) - run.len;
     base = __shfl(base, run.head, 64);

@@ -1250,13 +1250,11 @@ __global__ void __launch_bounds__(kTileW)
       const int s = t + k * kTileW;
       if (s < total) txy[s] = rv[k];
     }
-#if SC_WG_CELL_TABLE & 2
     if constexpr (GROUP && FUSED) {  // the pressures' array is free from here on: it takes the workgroup's cell table (below)
       int* tkey = reinterpret_cast<int*>(tP);
       cell_tab_clear(tkey, tkey + kCellTabSlots);
       if (t == 0) tkey[2 * kCellTabSlots] = 0;  // waves that have added their particles
     }
-#endif
     __syncthreads();
     SC_STAMP_B(4);
     if (active) {
@@ -1294,7 +1292,6 @@ __global__ void __launch_bounds__(kTileW)
       if (cnext >= 0) wslotS[i] = wsn;
     }
     SC_STAMP_B(18);
-#if SC_WG_CELL_TABLE & 2
     if (GROUP && in_lds) {
       // pile-up regime: the workgroup's particles are grouped by cell in LDS (cell_tab_*: sc_kernels.h), and the wave that
       // adds its particles last sends one atomic per cell for all four -- no barrier: a wave's LDS operations execute in
@@ -1313,9 +1310,9 @@ __global__ void __launch_bounds__(kTileW)
           if (k >= 0) atomicAdd(&cellCount[k], tcnt[s]);
         }
       }
-    } else
-#endif
-    count_cells<GROUP>(cnext, cellCount);  // every lane of the wave takes part
+    } else {
+      count_cells<GROUP>(cnext, cellCount);  // every lane of the wave takes part
+    }
     SC_STAMP_B(19);
     // slabs: the coming tick's halo message is packed here too (same rule and same pre-wall-fix position as
     // k_halo_pack); a workgroup-uniform branch, every lane of the wave takes part

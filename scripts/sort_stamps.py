@@ -32,13 +32,13 @@ def show(k, title, cols, names):
         print(f"    {label:44s} median {np.median(dt[:, j]):8.0f}   mean {dt[:, j].mean():8.0f}   p95 {np.percentile(dt[:, j], 95):8.0f}   p99 {np.percentile(dt[:, j], 99):8.0f}   slowest 1 % of waves: mean {dt[slow, j].mean():8.0f}")
     idx = np.flatnonzero(ok)[slow]
     print(f"    the slowest 1 % of waves: mean life {life[slow].mean():.0f} cycles; their wave numbers (of {waves}): " + " ".join(str(i) for i in idx[:: max(1, len(idx) // 24)]))
-# a wave of the scatter that is not scrambled never takes stamp 2: report the two kinds apart
+# only the grouping variant of the scatter (pile-up regime: the workgroup's cell table) takes stamp 2: report the two kinds apart
 st = buf[4, :waves]
 scr = st[:, 2] > st[:, 1]
-print(f"scatter: {scr.sum()} of {waves} waves grouped their lanes by cell (scrambled)")
+print(f"scatter: {scr.sum()} of {waves} waves went through the workgroup's cell table")
 keep = buf[4, :waves].copy()
 buf[4, :waves][~scr] = 0
-show(4, "scatter, scrambled waves", [0, 1, 2, 3, 4], ["cell, x, id, live count loaded", "lanes grouped by cell (12 rounds)", "bucket starts + returning atomics", "key and cell stored"])
+show(4, "scatter, cell table", [0, 1, 2, 3, 4], ["cell, x, id, live count loaded", "grouped by cell in the workgroup's LDS table", "bucket starts + returning atomics (one per cell and workgroup)", "key and cell stored"])
 buf[4, :waves] = keep
 buf[4, :waves][scr] = 0
 show(4, "scatter, waves in runs", [0, 1, 3, 4], ["cell, x, id, live count loaded", "runs, bucket starts + returning atomics", "key and cell stored"])
