@@ -351,6 +351,68 @@ def test_pile_up_ticks_match_the_oracle(sc, noise):
         p, v = gp, gv
 
 
+def test_cell_tables_with_every_cell_on_one_slot(sc):
+    """The workgroup cell tables of the pile-up variants (scatter and pass B's fused cell count: cell_tab_* in
+    csrc/sc_kernels.h) on the worst input for their hash: hundreds of particles, each alone in a cell, whose cells all hash
+    to ONE slot -- a workgroup of the sorted order then walks a single probing chain through its table -- beside the pile
+    that makes the host launch those variants.  Three ticks against the oracle."""
+    from oracle.scene import OracleCrate
+    from oracle.tick import remove_outside, tick_core
+    from oracle.world import World
+    d = 0.0025  # 400 x 400 cells: ~300 of them per slot of the 512-slot table
+    r = d / 2
+    # the library's grid (build_world in csrc/sandcrate_hip.hip): local cell = (row - row0) * ncols + (col - col0)
+    cmin, cmax = int(np.floor(-r / d)) - 3, int(np.floor((1 + r) / d)) + 3
+    row0 = col0 = cmin - 1
+    ncols = cmax - cmin + 3
+    cx, cy = np.meshgrid(np.arange(12, 388), np.arange(12, 388))
+    cx, cy = cx.ravel(), cy.ravel()
+    cell = (cy - row0) * ncols + (cx - col0)
+    slot = ((cell.astype(np.uint64) * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)) >> np.uint64(23)
+    pick = np.flatnonzero(slot == np.bincount(slot.astype(np.int64)).argmax())
+    assert len(pick) >= 256
+    rs = np.random.RandomState(5)
+    singles = np.column_stack((cx[pick] + 0.5, cy[pick] + 0.5)) * d
+    pile = np.array([200 * d, 100 * d]) + rs.rand(400, 2) * d * 0.98
+    p = np.vstack((singles, pile))
+    p = p[rs.permutation(len(p))]
+    p0 = p.copy()
+    v = np.zeros_like(p)
+    n = len(p)
+    wc = wave_world(sc, d, 0.0)
+    wc.coefficients["max_particles"] = n
+    crate = sc.Crate(wc, noise="none", capacity=n + 64)
+    crate.particles = p
+    crate.particle_velocities = v
+    orc = OracleCrate(World(wc.rigid_bodies, [], dict(wc.coefficients)))
+    ids = np.arange(n)
+    for t in range(3):
+        crate.physics_tick()
+        for b in orc.rigid_bodies:
+            b.advance(orc.coef["dt"])
+        p, v, ids = remove_outside(p, v, orc.coef["particle_radius"], ids)
+        out = tick_core(p, v, orc.segments, orc.body_states(), orc.coef, eta_u01=None)
+        gp, gv, gpr, gids = crate.engine.download()
+        assert np.array_equal(gids, ids)
+        np.testing.assert_allclose(gp, out["particles"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(gv, out["velocities"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(gpr, out["pressure"], rtol=1e-9, atol=1e-12)
+        p, v = gp, gv
+    # the same ticks in one run() -- pass B's fused cell count (the table without a barrier) instead of k_wall_bin's --
+    # end in the same state, bit for bit
+    wc2 = wave_world(sc, d, 0.0)
+    wc2.coefficients["max_particles"] = n
+    fused = sc.Crate(wc2, noise="none", capacity=n + 64)
+    fused.particles = p0
+    fused.particle_velocities = np.zeros_like(p0)
+    fused.run(1)
+    fused.synchronize()  # (the host has seen the first tick's big bucket: the next call launches the grouping variants)
+    fused.run(2)
+    fp, fv, fpr, fids = fused.engine.download()
+    assert np.array_equal(fids, gids)
+    assert np.array_equal(fp, gp) and np.array_equal(fv, gv) and np.array_equal(fpr, gpr)
+
+
 def test_pile_up_tick_does_not_depend_on_the_storage_order(sc, tmp_path):
     """The contract workload run into its pile-up regime (262,144 particles, tick 240: cells of thousands, particles
     crossing cells every tick).  A context restored from a checkpoint holds the particles in upload order instead of
