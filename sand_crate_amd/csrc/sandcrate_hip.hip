@@ -96,6 +96,7 @@ struct sc_ctx {
   unsigned scanStamp = 0;                  // ... and the stamp of its last launch
   int scan_max_polls = kScanMaxPolls;      // ... and how often a workgroup asks for a predecessor's total before it gives up (sc_set_scan_patience)
   int2* sortTasks = nullptr;  // k_sort_big's task list (cell, chunk | length): the scan writes it
+  bool piles_now = false;     // the hint "big buckets exist", latched once per tick (sc_step_begin)
   RcclComm comm = nullptr;  // RCCL communicator of the slab chain (sc_comm_init), or null
   int comm_rank = -1, comm_world = 0;
   double *haloL = nullptr, *haloR = nullptr;  // send buffers of the last sc_halo_pack (caller-owned device memory)
@@ -513,7 +514,9 @@ void launch_pass_a(sc_ctx* c, int kernel_id) {
 // Big buckets were seen by the last scan the host knows about (an unsynchronised, possibly stale hint in host-mapped
 // memory): the tick sorts its big buckets before ranking them and its cell counts group scrambled waves by cell.
 // Both only cost time when they are wrong; results do not depend on the choice.
-bool piles_expected(const sc_ctx* c) { return c->force_rank_big || *(volatile int*)c->bigHintHost > 0; }
+// (latched by sc_step_begin: every launch of a tick sees the same answer -- the sort of the big buckets and the grouping
+// variants of scatter, search and force kernel go together)
+bool piles_expected(const sc_ctx* c) { return c->piles_now; }
 
 template <int NOISE, bool FUSED, bool MON = false>
 void launch_pass_b(sc_ctx* c, const WallInputs& wn, int part = 0) {
@@ -817,6 +820,9 @@ int sc_step_begin(sc_ctx* c) {
   const World& w = c->w;
   int grid = grid_for(launch_bound(c));
   int cap = (int)c->cap;
+  // big buckets were seen by the last scan the host knows about (an unsynchronised, possibly stale hint in host-mapped
+  // memory), read ONCE per tick
+  c->piles_now = c->force_rank_big || *(volatile int*)c->bigHintHost > 0;
   if (c->prebinned) {
     // the previous sc_step_finish ran K1 of this tick with the promised inputs: they must be the inputs
     const WallInputs now = wall_inputs_of(w);

@@ -41,6 +41,12 @@ namespace sc {
 #ifndef SC_LEAD_IN
 #define SC_LEAD_IN 1
 #endif
+#ifndef SC_COOP_FAST
+#define SC_COOP_FAST 1
+#endif
+#ifndef SC_SERIAL_ONCE
+#define SC_SERIAL_ONCE 1
+#endif
 #ifndef SC_CAP_A
 #define SC_CAP_A 1024
 #define SC_CAP_AW 1536
@@ -235,6 +241,7 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
         } else {
           const int lane = t & 63, wave0 = t & ~63;
           int pos = first, left = want ? count : 0;
+          bool fresh = true;  // this thread has not walked its serial stretch of this scan yet
           probe.scan_begins(left);
           probe.clock_other();
           for (;;) {
@@ -282,7 +289,17 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
             {
               const int avail = step > 0 ? ws + CAP - pos : pos - ws + 1;  // slots of the window from pos on
               const int lim = left <= avail ? left : (avail & ~(kWinBatch - 1));
+#if SC_SERIAL_ONCE
+              // a thread walks kSerial candidates on its own ONCE per scan, in the first window that holds its position:
+              // what is left after that is a long walk (the serial stretch ends most scans), and in the windows that follow
+              // its next 32 candidates would cost the wave this loop's eight iterations and spare the wave-wide turn nothing
+              // (the heaviest tiles of a pile-up: nine windows, 45 k of 160 k cycles in this loop)
+              const bool mine_now = left > 0 && inside(pos);
+              const int cnt = mine_now && fresh ? min(lim, kSerial) : 0;
+              fresh = fresh && !mine_now;
+#else
               const int cnt = left > 0 && inside(pos) ? min(lim, kSerial) : 0;
+#endif
               const int base = pos - ws;
               unsigned lw = lo0 + (unsigned)C * kRow;
               bool stopped = false;
@@ -363,9 +380,15 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
                 for (int c = 0; c < kCoop; ++c) {
                   if (!stopped && c * 64 < nc) {  // wave-uniform
                     const bool valid = c * 64 + lane < nc;
-                    const int verdict = valid ? window(q[c].x, oxi) : 1;
                     const double dx = q[c].x - oxi, dy = q[c].y - oyi;
-                    const bool hit = verdict == 2 && dx * dx + dy * dy <= w.t_nbr;
+                    const bool near = dx * dx + dy * dy <= w.t_nbr;
+#if SC_COOP_FAST
+                    // 64 candidates none of which is within the distance or past the window's end (the rule in these
+                    // walks: a sparse particle beside a pile of thousands) leave nothing to record: no verdicts, no ranks
+                    if (!__ballot(valid && (near || window(q[c].x, oxi) == 0))) continue;
+#endif
+                    const int verdict = valid ? window(q[c].x, oxi) : 1;
+                    const bool hit = verdict == 2 && near;
                     const unsigned long long stopm = __ballot(verdict == 0);
                     const int nlive = stopm ? __ffsll(stopm) - 1 : 64;  // candidates ahead of the stop
                     const unsigned long long hitm = __ballot(hit && lane < nlive);

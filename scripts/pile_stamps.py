@@ -41,7 +41,7 @@ for k, label in ((0, "pass A"), (1, "pass B")):
         order = np.argsort(life)[-12:]
         for o in order:
             w = int(st[o, 14])
-            print(f"      slow wave: life {life[o]:7.1f} us  entries {int(st[o,10])}  tile {int(st[o,11])}  rounds {int(st[o,12])} stagings {int(st[o,13]) & 255} inner steps {(int(st[o,13]) >> 8) & 0xffffff} (scan2: {int(st[o,13]) >> 40}) coop {int(st[o,15])} sumC before/after scan2 {int(st[o,9]) & 0xffffffff}/{int(st[o,9]) >> 32} wants {w&255} {(w>>8)&255} {(w>>16)&255} {(w>>24)&255}  phases " + " ".join(f"{x:.0f}" for x in np.diff(st[o, :9])[:4]))
+            print(f"      slow wave: life {life[o]:7.1f} us  entries {int(st[o,10])}  tile {int(st[o,11])}  rounds {int(st[o,12])} stagings {int(st[o,13]) & 255} inner steps {(int(st[o,13]) >> 8) & 0xffffff} (scan2: {int(st[o,13]) >> 40}) coop {int(st[o,15])} sumC before/after scan2 {int(st[o,9]) & 0xffffffff}/{int(st[o,9]) >> 32} wants {w&255} {(w>>8)&255} {(w>>16)&255} {(w>>24)&255}  phases " + " ".join(f"{x:.0f}" for x in np.diff(st[o, :9])[:4]) + "  windowed: " + " ".join(f"{nm}={st[o, 16 + q]:.0f}" for q, nm in enumerate(["rounds+barriers", "staging", "serial", "wave-wide", "between"])))
         # how the kernel's critical path looks: start/end of waves relative to the first start (ticks -> us)
         t0 = st[:, 0].min()
         print(f"      kernel span by stamps {(st[:, 8].max() - t0) / 2100:.1f} us; waves starting after 100 us: {(st[:,0] - t0 > 100 * 2100).sum()}; last start {(st[:,0].max() - t0) / 2100:.1f} us")

@@ -40,3 +40,5 @@ for k, label in order:
           f"p99 {np.percentile(life, 99):6.2f} max {life.max():6.2f}; last start {start.max():6.2f}; "
           f"ends: 50% {es[len(es) // 2]:6.2f} 90% {es[int(len(es) * .9)]:6.2f} 99% {es[int(len(es) * .99)]:6.2f} us")
     prev_end = b
+if len(sys.argv) > 3:  # keep the raw stamps of the two passes (scripts/tile_order_sim.py)
+    np.savez_compressed(sys.argv[3], a=buf[0][: (n + 63) // 64], b=buf[passb][: (n + 63) // 64])
