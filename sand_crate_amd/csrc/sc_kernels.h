@@ -1070,12 +1070,23 @@ template <int NOISE>
 __device__ __forceinline__ double pair_origin(const World& w, double p) {
   return NOISE == SC_NOISE_COUNTER ? p + w.eta_half : p;
 }
+// The hash's two 64-bit constants held in VECTOR registers (pass B's unrolled pair loop: the kernel has vector registers
+// to spare -- four waves per SIMD by its LDS -- and no scalar ones, so the compiler re-materialised both constants with
+// four s_mov per pair)
+struct NoiseRegs {
+  uint64_t gold, mix;
+};
+__device__ __forceinline__ NoiseRegs noise_regs() {
+  uint64_t g = kGold, m = kMix;
+  asm volatile("" : "+v"(g), "+v"(m));
+  return NoiseRegs{g, m};
+}
 template <int NOISE>
 __device__ __forceinline__ void pair_offset(const World& w, uint64_t z, int slot, const double* __restrict__ eta, int off,
-                                            double dx, double dy, double& rx, double& ry) {
+                                            double dx, double dy, double& rx, double& ry, uint64_t mix = kMix) {
   if (NOISE == SC_NOISE_COUNTER) {
     z ^= z >> 32;
-    z *= kMix;
+    z *= mix;
     z ^= z >> 32;
     rx = fma((double)(uint32_t)(z >> 32), -w.eta_scale, dx);
     ry = fma((double)(uint32_t)z, -w.eta_scale, dy);

@@ -25,6 +25,7 @@
 // an IEEE sqrt and divide.
 #pragma once
 #include <climits>
+#include <type_traits>
 
 #include "sc_kernels.h"
 
@@ -43,6 +44,9 @@ namespace sc {
 #endif
 #ifndef SC_COOP_FAST
 #define SC_COOP_FAST 1
+#endif
+#ifndef SC_B_LEAN_LOOP
+#define SC_B_LEAN_LOOP 1
 #endif
 #ifndef SC_SERIAL_ONCE
 #define SC_SERIAL_ONCE 1
@@ -219,7 +223,11 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
 #pragma unroll
             for (int k = 0; k < kBatch; ++k) {
               const double dx = q[k].x - xi, dy = q[k].y - yi;
+#ifdef SC_ABL_NOVALID
+              const bool near = (dx * dx + dy * dy <= w.t_nbr);  // (timing ablation only: reads past the range may hit)
+#else
               const bool near = (dx * dx + dy * dy <= w.t_nbr) & (v + k < count);
+#endif
               edge |= near & !(fabs(dx) < w.dsafe);
               inc[k] = near ? kRow : 0u;
             }
@@ -849,6 +857,26 @@ __global__ void __launch_bounds__(kTileW)
 // 256 particles, so that sixteen waves share a CU (a 64-byte record with the velocities allowed ten).  The
 // neighbors' start-of-tick velocities are only summed (crate.py:175, :319-323): they are staged into the
 // (x, y) array once the pair loop is done with it.
+// f(slot) for slot = S, S + 1, ... while slot < count, the slots compile-time constants and the tests NESTED: a lane leaves at
+// its count and the wave's exec mask only ever narrows (a flat `if (s < count)` per unrolled slot restores it every time:
+// four control instructions per slot instead of three, and a wave whose lanes are all done still visits every slot).
+template <int S, int N, class F>
+__device__ __forceinline__ void nested_slots_flat(const int count, F&& f) {  // (the flat form, for comparison)
+  if constexpr (S < N) {
+    if (S < count) f(std::integral_constant<int, S>{});
+    nested_slots_flat<S + 1, N>(count, f);
+  }
+}
+template <int S, int N, class F>
+__device__ __forceinline__ void nested_slots(const int count, F&& f) {
+  if constexpr (S < N) {
+    if (S < count) {
+      f(std::integral_constant<int, S>{});
+      nested_slots<S + 1, N>(count, f);
+    }
+  }
+}
+
 struct PairSums {
   double tx, ty;    // the velocity change of apply_tension + the particle part of apply_pressure, dt included
   double mtx, mty;  // force monitor only: the share of apply_tension in it
@@ -896,28 +924,42 @@ __device__ __forceinline__ PairSums pass_b_pairs(const World& w, const Tile& tl,
   const double ox = pair_origin<NOISE>(w, xi), oy = pair_origin<NOISE>(w, yi);
   const int off = (NOISE == SC_NOISE_HOST) ? offById[idi] : 0;
   const uint64_t zbase = noise_base(w.noise_key, idi);
-  const double k_ss = w.k_ss, k_pp = w.k_pp, k_0 = w.k_0;
+  const double k_ss = w.k_ss, k_pp = w.k_pp;
+  double k_0 = w.k_0;
+#if SC_B_LEAN_LOOP
+  asm volatile("" : "+v"(k_0));  // (held in a vector register: as the third operand of an fma next to k_pp it was moved there once per pair)
+#endif
   double tx = 0, ty = 0, mtx = 0, mty = 0;
-#pragma unroll
-  for (int s = 0; s < kMaxNbr; ++s) {
-    if (s < Cn) {
-      XY op, os;
-      double oP;
-      load(entry(s), op, os, oP);
-      double rx, ry;
-      pair_offset<NOISE>(w, zbase + (uint64_t)s * kGold, s, eta, off, ox - op.x, oy - op.y, rx, ry);
-      const double rinv = rsqrt_nr(rx * rx + ry * ry);
-      const double dot = ((sxi - os.x) * rx + (syi - os.y) * ry) * rinv;  // (s_i - s_j) . n_ij
-      const double wr = fma(dot, k_ss, fma(Pi + oP, k_pp, k_0)) * rinv;
-      tx += wr * rx;
-      ty += wr * ry;
-      if constexpr (MON) {  // the tension share on its own, next to -- not instead of -- the sums above
-        const double wt = fma(dot, k_ss, fma(Pi + oP, w.dt, k_0)) * rinv;
-        mtx += wt * rx;
-        mty += wt * ry;
-      }
+  // one pair: slot s (a compile-time constant) with the hash key z
+  auto pair = [&](auto slot, const uint64_t z, const uint64_t mix) {
+    constexpr int s = decltype(slot)::value;
+    XY op, os;
+    double oP;
+    load(entry(s), op, os, oP);
+    double rx, ry;
+    pair_offset<NOISE>(w, z, s, eta, off, ox - op.x, oy - op.y, rx, ry, mix);
+    const double rinv = rsqrt_nr(rx * rx + ry * ry);
+    const double dot = ((sxi - os.x) * rx + (syi - os.y) * ry) * rinv;  // (s_i - s_j) . n_ij
+    const double wr = fma(dot, k_ss, fma(Pi + oP, k_pp, k_0)) * rinv;
+    tx += wr * rx;
+    ty += wr * ry;
+    if constexpr (MON) {  // the tension share on its own, next to -- not instead of -- the sums above
+      const double wt = fma(dot, k_ss, fma(Pi + oP, w.dt, k_0)) * rinv;
+      mtx += wt * rx;
+      mty += wt * ry;
     }
-  }
+  };
+#if SC_B_LEAN_LOOP
+  // nested slot tests (nested_slots), the hash's running key and its constants in vector registers (noise_regs)
+  const NoiseRegs nr = noise_regs();
+  uint64_t z = zbase;
+  nested_slots<0, kMaxNbr>(Cn, [&](auto slot) {
+    pair(slot, z, nr.mix);
+    z += nr.gold;
+  });
+#else
+  nested_slots_flat<0, kMaxNbr>(Cn, [&](auto slot) { pair(slot, zbase + (uint64_t) decltype(slot)::value * kGold, kMix); });
+#endif
   return PairSums{tx, ty, mtx, mty};
 }
 
@@ -937,20 +979,23 @@ __device__ __forceinline__ void pass_b_finish(const World& w, const Tile& tl, co
                                               double (&mon)[kMonPhases], const unsigned near_now = ~0u) {
   auto norm2 = [](double a, double b) { return sqrt(a * a + b * b); };
   double ux = 0, uy = 0;
-#pragma unroll
-  for (int s = 0; s < kMaxNbr; ++s) {
-    if (s < Cn) {
-      XY ov;
-      if constexpr (LDS) {
-        ov = tv[entry(s)];
-      } else {
-        const int j = entry_index(tl, entry(s));
-        ov = svv[j];
-      }
-      ux += ov.x;  // crate.py:175: the neighbors' start-of-tick velocities
-      uy += ov.y;
+  auto add_velocity = [&](auto slot) {
+    constexpr int s = decltype(slot)::value;
+    XY ov;
+    if constexpr (LDS) {
+      ov = tv[entry(s)];
+    } else {
+      const int j = entry_index(tl, entry(s));
+      ov = svv[j];
     }
-  }
+    ux += ov.x;  // crate.py:175: the neighbors' start-of-tick velocities
+    uy += ov.y;
+  };
+#if SC_B_LEAN_LOOP
+  nested_slots<0, kMaxNbr>(Cn, add_velocity);
+#else
+  nested_slots_flat<0, kMaxNbr>(Cn, add_velocity);
+#endif
 
   // 4. per-particle epilogue
   double Ux = 0, Uy = 0, Cx = 0, Cy = 0, V = 0;
