@@ -130,7 +130,7 @@ struct sc_ctx {
   int64_t cellAlloc = 0;
   double* wrec[2] = {nullptr, nullptr};  // wall records of even / odd ticks
   int* nbr = nullptr;              // neighbor table of tiles beyond 65535 entries: -(sorted index + 1), 32 bit
-  NbrRow* rows = nullptr;  // neighbor table: a 48-byte row per sorted particle (twenty 16-bit tile slots and the count)
+  NbrRow* rows = nullptr;  // neighbor table: a 32-byte row per sorted particle (twenty 12-bit tile slots and the count)
   double* P = nullptr;
   XY *sxy = nullptr, *svv = nullptr, *snn = nullptr;  // the sorted positions and velocities, the surface normals: 16-byte pairs
   int* counters = nullptr;
@@ -1177,7 +1177,7 @@ int sc_download_neighbors(sc_ctx* c, int64_t* ids, int32_t* counts, int64_t* nei
   bool any_big = false;  // a block whose tile exceeds 16-bit slots: the 32-bit table holds -(index + 1)
   for (int64_t b = 0; b < nblocks; ++b) {
     const Tile tl = tile_of(b * kTileW);
-    any_big |= tl.n0 + tl.n1 + tl.n2 > kSlotMax;
+    any_big |= tl.n0 + tl.n1 + tl.n2 > kRowSlotMax;
   }
   for (int s = 0; s < kMaxNbr && neighbors; ++s) {
     if (any_big) {
@@ -1185,15 +1185,15 @@ int sc_download_neighbors(sc_ctx* c, int64_t* ids, int32_t* counts, int64_t* nei
       HIPCHK(hipStreamSynchronize(c->stream));
     }
     for (int64_t k = 0; k < n; ++k) {
-      if (s >= (int)rows[k].w[kRowCount]) continue;
+      if (s >= row_count(rows[k])) continue;
       const Tile tl = tile_of(k);
-      const bool big = tl.n0 + tl.n1 + tl.n2 > kSlotMax;
+      const bool big = tl.n0 + tl.n1 + tl.n2 > kRowSlotMax;
       neighbors[k * kMaxNbr + s] = id[entry_index(tl, big ? slot[k] : row_entry(rows[k], s))];
     }
   }
   for (int64_t k = 0; k < n; ++k) {
     if (ids) ids[k] = id[k];
-    if (counts) counts[k] = (int32_t)rows[k].w[kRowCount];
+    if (counts) counts[k] = (int32_t)row_count(rows[k]);
     if (fixed_xy) {
       fixed_xy[2 * k] = hxy[2 * k];
       fixed_xy[2 * k + 1] = hxy[2 * k + 1];

@@ -999,7 +999,11 @@ __global__ void __launch_bounds__(kReorderBlock)
 
 // K5-K7 (neighbor search, pass A, pass B) are the LDS-tiled kernels of sc_tiled.h.
 
-constexpr int kRowWords = 12, kRowCount = 10;  // a neighbor-table row in 32-bit words, and the word that holds the count (NbrRow)
+// a neighbor-table row (sc_tiled.h: NbrRow) in 32-bit words; the count sits in the top five bits of the last one
+constexpr int kRowWords = 8, kRowCountWord = 7, kRowCountShift = 27;
+__device__ __host__ __forceinline__ int row_count_of(const unsigned int* rows, size_t i) {
+  return (int)(rows[i * kRowWords + kRowCountWord] >> kRowCountShift);
+}
 
 // Sum and maximum of the neighbor counts, on demand (sc_step_stats).  Kept out of the search kernel:
 // one atomic per workgroup on a single address serialises at ~12 ns each and dominated it.
@@ -1010,7 +1014,7 @@ __global__ void __launch_bounds__(kBlock) k_count_stats(int* __restrict__ counte
   long long sum = 0;
   int mx = 0, walls = 0;
   for (int i = threadIdx.x; i < n; i += kBlock) {
-    int c = (int)rows[(size_t)i * kRowWords + kRowCount];  // (the count of particle i's table row: sc_tiled.h, NbrRow)
+    int c = row_count_of(rows, (size_t)i);  // (the count of particle i's table row: sc_tiled.h, NbrRow)
     sum += c;
     mx = max(mx, c);
     walls += wslot[i] >= 0;  // particles with a wall record (crate.py:229: V_i not empty)
@@ -1043,7 +1047,7 @@ __global__ void __launch_bounds__(kBlock) k_count_stats(int* __restrict__ counte
 __global__ void k_count_by_id(const int* __restrict__ counters, const int* __restrict__ id,
                               const unsigned int* __restrict__ rows, int* __restrict__ cntById) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < counters[C_NT]) cntById[id[i]] = (int)rows[(size_t)i * kRowWords + kRowCount];
+  if (i < counters[C_NT]) cntById[id[i]] = row_count_of(rows, (size_t)i);
 }
 
 // Collider offset eta_ij of crate.py:169 for slot `slot` of a particle.  `z` is the particle's

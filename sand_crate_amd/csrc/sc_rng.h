@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(kSmallBlock)
   const int n = counters[C_NT];
   for (int k = tid; k < ids; k += kSmallBlock) cntById[k] = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += kSmallBlock) cntById[id[i]] = (int)rows[(size_t)i * kRowWords + kRowCount];
+  for (int i = tid; i < n; i += kSmallBlock) cntById[id[i]] = row_count_of(rows, (size_t)i);
   if (tid == 0) carry_s = 0;
   __syncthreads();
   // exclusive scan over the ids, every thread a run of consecutive ids: its loads are all in flight together (one

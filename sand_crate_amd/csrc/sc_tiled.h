@@ -65,17 +65,45 @@ constexpr int kTileCapB = SC_CAP_B;   // pass B tile: (x, y), (sx, sy), P of the
 #define SC_DENSE_TILE (SC_TILE_W * 43 / 10)
 #endif
 constexpr int kDenseTile = SC_DENSE_TILE;  // 1100 entries for 256 particles (the usual tile has ~800)
-constexpr int kSlotMax = 65535;  // lists are staged as u16 tile slots in pass A
+constexpr int kSlotMax = 65535;    // lists are staged as u16 tile slots in pass A
+constexpr int kRowSlotMax = 4095;  // ... and stored as 12-bit slots of the tile pass B will stage
 
-// The neighbor table: one 48-byte row per sorted particle -- twenty entries of 16 bits (tile slots, below) and the count --
-// written by pass A in three 16-byte stores and read by pass B in three 16-byte loads.  (Rounds 1-3 kept it slot-major,
-// entry s of all particles contiguous, so that a wave's access to one entry was one coalesced request: twenty 2-byte loads
-// per particle in pass B and up to twenty 2-byte stores in pass A, plus a separate count array.)
+// The neighbor table: one 32-byte row per sorted particle -- twenty entries of 12 bits (slots of the tile published in
+// tileBoundsT, below: entry s in bits 12 s .. 12 s + 11) and, in the top five bits, the count -- written by pass A in two
+// 16-byte stores and read by pass B in two 16-byte loads.  Neither pass has bandwidth to spare (pass B without its pair
+// loop still takes 41 of its 55 us, pass A without search and pair math 29 of 54: what they move at the rate the fabric
+// sustains), and the table was a third of what pass A writes.  A tile whose published ranges hold more than 4,095 entries
+// -- a block beside a pile whose lists reach across thousands -- keeps its entries in the 32-bit table instead (`nbr`).
+// (Round 4 began with twenty 16-bit entries and the count in 48 bytes; rounds 1-3 kept the table slot-major, entry s of all
+// particles contiguous: twenty 2-byte loads per particle in pass B and up to twenty 2-byte stores in pass A.)
 struct alignas(16) NbrRow {
-  unsigned int w[12];  // w[0..9]: entries 2k (low half) and 2k + 1 (high half); w[10]: the count; w[11]: unused
+  unsigned int w[kRowWords];
 };
-static_assert(sizeof(NbrRow) == 4 * kRowWords && kMaxNbr == 2 * kRowCount, "a row is twenty 16-bit entries, the count and padding");
-__device__ __host__ __forceinline__ int row_entry(const NbrRow& r, int s) { return (int)((r.w[s >> 1] >> (16 * (s & 1))) & 0xFFFFu); }
+static_assert(sizeof(NbrRow) == 32 && 12 * kMaxNbr <= 32 * kRowCountWord + kRowCountShift && kMaxNbr < 32, "twenty 12-bit entries and a 5-bit count");
+__device__ __host__ __forceinline__ int row_entry(const NbrRow& r, int s) {
+  const int b = 12 * s, k = b >> 5, sh = b & 31;
+  unsigned int v = r.w[k] >> sh;
+  if (sh > 20) v |= r.w[k + 1] << (32 - sh);  // (the entry straddles two words; the last entry ends inside word 7)
+  return (int)(v & 0xFFFu);
+}
+__device__ __host__ __forceinline__ int row_count(const NbrRow& r) { return (int)(r.w[kRowCountWord] >> kRowCountShift); }
+// a thread's list as pass A holds it -- ten words of two 16-bit slots -- into a row: every pair of slots becomes 24 bits,
+// four pairs fill three words
+__device__ __forceinline__ NbrRow row_pack(const unsigned int (&lw)[kMaxNbr / 2], int count) {
+  unsigned int p[kMaxNbr / 2];
+#pragma unroll
+  for (int k = 0; k < kMaxNbr / 2; ++k) p[k] = (lw[k] & 0xFFFu) | ((lw[k] >> 4) & 0xFFF000u);
+  NbrRow r;
+  r.w[0] = p[0] | (p[1] << 24);
+  r.w[1] = (p[1] >> 8) | (p[2] << 16);
+  r.w[2] = (p[2] >> 16) | (p[3] << 8);
+  r.w[3] = p[4] | (p[5] << 24);
+  r.w[4] = (p[5] >> 8) | (p[6] << 16);
+  r.w[5] = (p[6] >> 16) | (p[7] << 8);
+  r.w[6] = p[8] | (p[9] << 24);
+  r.w[7] = (p[9] >> 8) | ((unsigned int)count << kRowCountShift);
+  return r;
+}
 
 // A thread's list while it is being built, in LDS: kMaxNbr entries of 16 bits and SC_SCAN_BATCH spare ones (the writes of a
 // full list, below), thread-major -- the row is then copied to the table as it is.  The stride is an odd number of
@@ -165,7 +193,9 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
       return sxy[j];
     }
   };
-  const bool slots_fit = total <= kSlotMax;
+  // (a launch that builds the lists numbers the tile's slots in 16 bits; one that reads them back from the table -- the
+  // density pass of SC_NOISE_HOST on the published tile -- finds them there only if the row's 12 bits could hold them)
+  const bool slots_fit = total <= (ENUM ? kSlotMax : kRowSlotMax);
 
   // 3. neighbor list of particle i: four serial scans in the reference's order, entries are tile slots
   int C = 0;
@@ -505,10 +535,10 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
   } else if (live) {
     // lists were built by an earlier launch: bring them in
     const NbrRow row = rows[i];
-    C = (int)row.w[kRowCount];
+    C = row_count(row);
     if (slots_fit) {
 #pragma unroll
-      for (int k = 0; k < kMaxNbr / 2; ++k) list.word(k, t) = row.w[k];
+      for (int k = 0; k < kMaxNbr / 2; ++k) list.word(k, t) = (unsigned)row_entry(row, 2 * k) | ((unsigned)row_entry(row, 2 * k + 1) << 16);
     }
   }
 
@@ -670,15 +700,25 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
   }
 
   SC_STAMP(0, 7);
-  // 5. lists out: the thread's row of the table -- its list as it stands in LDS, and the count -- in three 16-byte stores.
+  // 5. lists out: the thread's row of the table -- its list as it stands in LDS, twelve bits per entry, and the count -- in
+  // two 16-byte stores.
   // The table's slots refer to the ranges published in tileBoundsT -- for the usual tile the candidate ranges, for a tile
   // whose candidate ranges exceed pass B's LDS budget the reach of its lists, the entries renumbered (3b above).
   if (ENUM) {
     int nb[6] = {tl.a0, tl.a0 + tl.n0, tl.a1, tl.a1 + tl.n1, tl.a2, tl.a2 + tl.n2}, sub[3] = {0, 0, 0};
-    const bool trim = slots_fit && total > kTileCapB;  // uniform over the workgroup
+    bool trim = slots_fit && total > kTileCapB;  // uniform over the workgroup
+    bool in_rows = slots_fit;                     // the entries go into the rows (else: into the 32-bit table)
     if (trim) {
       if (!(STAGE && !LDS)) extremes();  // (a tile that staged its reach for the pair math has them in wkey already)
-      reach(nb, sub);
+      int rnb[6], rsub[3];
+      if (reach(rnb, rsub) <= kRowSlotMax) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) nb[k] = rnb[k];
+        sub[0] = rsub[0]; sub[1] = rsub[1]; sub[2] = rsub[2];
+      } else {  // lists that reach across more than a row's 12 bits can number (never a tile that staged its reach: that fits the window)
+        trim = false;
+        in_rows = false;
+      }
     }
     if (t == 0) {
       int* tbT = tileBoundsT + 6 * tile_id;
@@ -686,8 +726,10 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
     }
     if (live) {
       C = min(C, kMaxNbr);  // (never more by construction; the rows of the table end there)
-      NbrRow row;
-      if (slots_fit) {
+      unsigned int lw[kMaxNbr / 2];
+#pragma unroll
+      for (int k = 0; k < kMaxNbr / 2; ++k) lw[k] = 0u;
+      if (in_rows) {
         if (trim && !staged) {
           for (int s = 0; s < C; ++s) {
             const int e = list(s, t);
@@ -695,14 +737,11 @@ __device__ __forceinline__ void pass_a_body(const World& w, const Tile& tl, cons
           }
         }
 #pragma unroll
-        for (int k = 0; k < kMaxNbr / 2; ++k) row.w[k] = list.word(k, t);  // (entries from C on: whatever the scans left there)
-      } else {
-#pragma unroll
-        for (int k = 0; k < kMaxNbr / 2; ++k) row.w[k] = 0u;  // (the entries are in the 32-bit table)
+        for (int k = 0; k < kMaxNbr / 2; ++k) lw[k] = list.word(k, t);  // (entries from C on: whatever the scans left there)
+      } else if (slots_fit) {  // (a tile beyond 16-bit slots wrote the 32-bit table as it searched)
+        for (int s = 0; s < C; ++s) nbr[(size_t)s * cap + i] = -tile_index(tl, (int)list(s, t)) - 1;
       }
-      row.w[kRowCount] = (unsigned)C;
-      row.w[11] = 0u;
-      rows[i] = row;
+      rows[i] = row_pack(lw, C);
     }
   }
   SC_STAMP(0, 8);
@@ -1167,7 +1206,7 @@ __global__ void __launch_bounds__(kTileW)
   const int tb0 = tb[0], tb1 = tb[1], tb2 = tb[2], tb3 = tb[3], tb4 = tb[4], tb5 = tb[5];
   const int cpacked = cell[ic];
   const NbrRow row = rows[ic];
-  const int Craw = (int)row.w[kRowCount];
+  const int Craw = row_count(row);
   const int ws_raw = wslot[ic];
   const int idi = id[ic];
   const int n = counters[C_NT];
@@ -1237,7 +1276,7 @@ __global__ void __launch_bounds__(kTileW)
   // the table entry of slot s: from the row's packed words (the pair loops keep the ten words, not twenty entries, in
   // registers); a block inside one gigantic bucket reads indices from the 32-bit table instead
   const auto entry16 = [&](int s) -> int { return row_entry(row, s); };
-  const bool wide = total > kSlotMax;
+  const bool wide = total > kRowSlotMax;
   const auto entry_any = [&](int s) -> int { return wide ? nbr[(size_t)s * cap + ic] : row_entry(row, s); };
   SC_STAMP_VALUE_B(10, total);
   SC_STAMP_VALUE_B(11, tile_id);
