@@ -351,6 +351,63 @@ def test_pile_up_ticks_match_the_oracle(sc, noise):
         p, v = gp, gv
 
 
+def test_lists_that_reach_across_more_than_a_row_can_number(sc):
+    """A neighbor-table row holds twelve bits per entry: slots of the tile pass A publishes for pass B, up to 4,095.  Sparse
+    particles in the rows beside a pile of 6,000 in one cell are within reach of a handful of its particles each, spread
+    over the whole of the pile's x order -- the published ranges of their tiles hold far more than 4,095 entries, so those
+    tiles keep their entries in the 32-bit table (csrc/sc_tiled.h: kRowSlotMax).  Two ticks against the oracle."""
+    from oracle.scene import OracleCrate
+    from oracle.tick import remove_outside, tick_core
+    from oracle.world import World
+    d = 0.012
+    rs = np.random.RandomState(11)
+    cell = lambda cx, cy: np.array([cx * d, cy * d])  # noqa: E731
+    parts = [
+        cell(30, 40) + rs.rand(6000, 2) * d * 0.98,                                         # the pile: one cell, full
+        cell(29, 41) + np.column_stack((rs.rand(16) * 3 * d, 0.955 * d + rs.rand(16) * 0.02 * d)),  # above it, at the far side of their cells
+        cell(29, 39) + np.column_stack((rs.rand(16) * 3 * d, 0.005 * d + rs.rand(16) * 0.02 * d)),  # below it, likewise
+        rs.rand(1500, 2) * 0.9 + 0.05,
+    ]
+    n_pile = 6000
+    p = np.vstack(parts)
+    perm = rs.permutation(len(p))
+    p = p[perm]
+    v = (rs.rand(len(p), 2) - 0.5) * 0.2 * d / (0.002 * d / 0.01)
+    n = len(p)
+    wc = wave_world(sc, d, 0.0)
+    wc.coefficients["max_particles"] = n
+    crate = sc.Crate(wc, noise="none", capacity=n + 64)
+    crate.particles = p
+    crate.particle_velocities = v
+    orc = OracleCrate(World(wc.rigid_bodies, [], dict(wc.coefficients)))
+    ids = np.arange(n)
+    row_of = perm  # the row of `parts` a particle came from, by id
+    for t in range(2):
+        crate.physics_tick()
+        for b in orc.rigid_bodies:
+            b.advance(orc.coef["dt"])
+        p, v, ids = remove_outside(p, v, orc.coef["particle_radius"], ids)
+        out = tick_core(p, v, orc.segments, orc.body_states(), orc.coef, eta_u01=None)
+        if t == 0:  # the geometry does what the docstring says: the lists of the particles above the pile -- a handful of
+            # sorted neighbors, one tile -- name pile particles more than 4,095 apart in the sorted order
+            q = out["fixed_positions"]
+            order = np.lexsort((q[:, 0], np.floor(q[:, 1] / d)))
+            rank = np.empty(len(q), dtype=np.int64)
+            rank[order] = np.arange(len(q))
+            nbrs, cnt = out["neighbor_table"], out["neighbor_counts"]
+            is_pile = row_of[ids] < n_pile  # (by position in the tick's arrays; upload order was shuffled)
+            above = np.flatnonzero((np.floor(q[:, 1] / d) == 41) & (np.floor(q[:, 0] / d) >= 29) & (np.floor(q[:, 0] / d) < 32))
+            named = np.concatenate([nbrs[i][:cnt[i]] for i in above])
+            named = named[is_pile[named]]
+            assert len(above) >= 8 and rank[named].max() - rank[named].min() > 4095
+        gp, gv, gpr, gids = crate.engine.download()
+        assert np.array_equal(gids, ids)
+        np.testing.assert_allclose(gp, out["particles"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(gv, out["velocities"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(gpr, out["pressure"], rtol=1e-9, atol=1e-12)
+        p, v = gp, gv
+
+
 def test_cell_tables_with_every_cell_on_one_slot(sc):
     """The workgroup cell tables of the pile-up variants (scatter and pass B's fused cell count: cell_tab_* in
     csrc/sc_kernels.h) on the worst input for their hash: hundreds of particles, each alone in a cell, whose cells all hash
